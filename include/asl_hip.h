@@ -1,0 +1,192 @@
+/*
+ * asl_hip.h -- C ABI of libaslhip.so: the MI355X (gfx950) kernels behind the video-ASL
+ * clip -> logits path.
+ *
+ * The reference snapshot defines no FFI or operator interface for this path (it holds no
+ * code: /root/reference/README.md:1 is the whole README, /root/reference/.gitignore:1-5
+ * the only other file).  Each entry point below therefore names the stock PyTorch CPU
+ * operator(s) it stands in for -- the ops the reference's "PyTorch CPU eager" forward
+ * would have called -- instead of a reference file:line.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller.  The library never
+ *     allocates, frees or retains memory, and keeps no mutable global state.
+ *   - Every launcher is asynchronous on the caller-supplied stream and returns
+ *     ASL_OK (0) or a negative ASL_E* code / positive hipError_t.  Geometry that a
+ *     kernel cannot execute safely is rejected with ASL_EINVAL before any launch.
+ *   - Activations are channels-last bf16 with an optional zero halo:
+ *         x[n][d + halo_d][h + halo][w + halo][c]      (d axis only for 3-D tensors)
+ *     so a padded convolution reads its zero padding from memory instead of testing
+ *     bounds.  Halo cells must be zero on entry and are never written.
+ *   - Physical channel counts of conv inputs are multiples of 32 (the stem's packed
+ *     layout, 4 channels per pixel, is the one exception and has its own packing).
+ */
+#ifndef ASL_HIP_H
+#define ASL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* asl_stream_t; /* == hipStream_t */
+
+enum {
+    ASL_OK = 0,
+    ASL_EINVAL = -1,   /* shape / alignment / bounds violation, nothing launched */
+    ASL_ENOTSUP = -2   /* valid request that no compiled kernel variant covers   */
+};
+
+int asl_version(void);
+const char* asl_strerror(int rc);
+
+/* ------------------------------------------------------------------------------------
+ * Addressing of one activation tensor as the gather-GEMM sees it: the element offset
+ * of "output row m" (m -> image n, depth d, row h, column w of the OUTPUT grid) is
+ *     n*sn + d*sd + h*sh + w*sw + off0
+ * For the input tensor this is the first element the receptive field touches; for the
+ * output / residual tensors it is channel 0 of the pixel.
+ * ---------------------------------------------------------------------------------- */
+typedef struct asl_geom {
+    int64_t sn;
+    int32_t sd, sh, sw;
+    int32_t off0;
+} asl_geom;
+
+/* Generic gather-GEMM:  y[m][co] = act( scale[co] * sum_{tap,c} x[row(m) + tap_off(tap) + c] *
+ *                                       w[co][tap*ck + c]  + bias[co] + res[m][co] )
+ * Stands in for nn.Conv2d / nn.Conv3d (bias=False) + BatchNorm(eval) + residual add +
+ * ReLU, and for nn.Linear (kd=kh=kw=1, od=oh=ow=1).
+ *   w      packed bf16 [w_rows][wk], wk = kd*kh*kw*ck, w_rows = cout rounded up to 128,
+ *          rows >= cout zero.
+ *   scale  fp32 [cout] or NULL (1.0);  bias fp32 [cout] or NULL (0.0)
+ *   res    bf16 residual or NULL;      y bf16 (out_f32 == 0) or fp32 (out_f32 == 1)
+ *   *_elems  allocation sizes in elements, used to reject out-of-bounds geometry.       */
+typedef struct asl_gemm_params {
+    int32_t nb, od, oh, ow;          /* output grid; M = nb*od*oh*ow            */
+    int32_t cout;
+    int32_t kd, kh, kw;              /* taps                                    */
+    int32_t ck;                      /* contiguous K elements per tap, % 32 == 0 */
+    int32_t tap_sd, tap_sh, tap_sw;  /* element offset between neighbouring taps */
+    asl_geom in, out, res;
+    int32_t relu;
+    int32_t out_f32;
+    int32_t w_rows;
+    int64_t x_elems, y_elems, res_elems;
+} asl_gemm_params;
+
+int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, const void* w,
+                         const float* scale, const float* bias, const void* res, void* y,
+                         asl_stream_t stream);
+
+/* nn.Conv2d(cin, cout, (kh,kw), stride, pad, bias=False) + BatchNorm2d(eval) [+ residual]
+ * [+ ReLU] on halo'd NHWC bf16.  x: [n][h+2*in_halo][w+2*in_halo][cin]; y is written at
+ * channel offset out_coff of a [n][oh+2*out_halo][ow+2*out_halo][out_ctot] tensor (so
+ * branches can write slices of one concatenated tensor); res (optional) has the same
+ * pixel grid as y with res_halo / res_ctot / res_coff.  Requires in_halo >= pad and
+ * cin % 32 == 0.  w packed as for asl_gather_gemm_bf16 with ck = cin, tap order (kh,kw). */
+typedef struct asl_conv2d_params {
+    int32_t n, h, w, cin, in_halo;
+    int32_t cout, kh, kw, stride, pad;
+    int32_t out_halo, out_ctot, out_coff;
+    int32_t res_halo, res_ctot, res_coff;
+    int32_t relu;
+    int32_t w_rows;
+} asl_conv2d_params;
+
+int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, const void* w,
+                         const float* scale, const float* bias, const void* res, void* y,
+                         asl_stream_t stream);
+
+/* The ResNet stem: nn.Conv2d(3, cout, 7, stride 2, pad 3, bias=False) + BatchNorm2d(eval) +
+ * ReLU.  x is the packed clip tensor written by asl_pack_clips / asl_preprocess_u8:
+ * [n][h+6][w+6][4] bf16 (channel 3 zero, halo 3).  w packed [w_rows][7*32]: for filter row
+ * r, 8 pixels x 4 channels with pixel 7 and channel 3 zero.  y: [n][h/2+2*out_halo][..][cout]. */
+typedef struct asl_stem_params {
+    int32_t n, h, w;
+    int32_t cout, out_halo;
+    int32_t w_rows;
+} asl_stem_params;
+
+int asl_stem7x7_bf16(const asl_stem_params* p, const void* x, const void* w,
+                     const float* scale, const float* bias, void* y, asl_stream_t stream);
+
+/* nn.Conv3d(cin, cout, (kd,kh,kw), stride, pad=k//2, bias=False) + BatchNorm3d(eval) + ReLU
+ * on halo'd NDHWC bf16: x [n][d+2*in_halo_d][h+2*in_halo][w+2*in_halo][cin]. */
+typedef struct asl_conv3d_params {
+    int32_t n, d, h, w, cin, in_halo_d, in_halo;
+    int32_t cout, kd, kh, kw, stride_d, stride, pad_d, pad;
+    int32_t out_halo_d, out_halo, out_ctot, out_coff;
+    int32_t relu;
+    int32_t w_rows;
+} asl_conv3d_params;
+
+int asl_conv3d_ndhwc_bf16(const asl_conv3d_params* p, const void* x, const void* w,
+                          const float* scale, const float* bias, void* y, asl_stream_t stream);
+
+/* nn.Linear on bf16 rows: y[m][n] = act(scale[n] * sum_k x[m][k] w[n][k] + bias[n] (+ res)).
+ * x bf16 [m][ldx] (k % 32 == 0, ldx >= k), w packed [w_rows][k], y bf16 or fp32 [m][ldy]. */
+typedef struct asl_linear_params {
+    int32_t m, n, k;
+    int32_t ldx, ldy, ldres;
+    int32_t relu, out_f32;
+    int32_t w_rows;
+} asl_linear_params;
+
+int asl_linear_bf16(const asl_linear_params* p, const void* x, const void* w,
+                    const float* scale, const float* bias, const void* res, void* y,
+                    asl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Layout / elementwise / pooling kernels (HBM-bound)
+ * ---------------------------------------------------------------------------------- */
+
+/* clips [n][3][s][s] (fp32 if in_f32 else bf16), i.e. the [B,T,3,S,S] forward() argument
+ * flattened over B*T  ->  packed stem input [n][s+6][s+6][4] bf16, halo and channel 3
+ * zeroed by this kernel. */
+int asl_pack_clips(const void* clips, int in_f32, int n, int s, void* y, asl_stream_t stream);
+
+/* F.interpolate(bilinear, align_corners=False, antialias=False) + /255 + (x-mean)/std:
+ * frames uint8 [n][h0][w0][3]  ->  packed stem input [n][s+6][s+6][4] bf16 (as above).
+ * If clips_f32 != NULL the normalised fp32 [n][3][s][s] tensor is written as well. */
+int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, int s,
+                      const float mean[3], const float std_[3], void* y, float* clips_f32,
+                      asl_stream_t stream);
+
+/* nn.MaxPool2d(3, 2, 1) on halo'd NHWC bf16 (c % 8 == 0).  Input values must be >= 0
+ * wherever a window overlaps the halo (true after ReLU): the zero halo then acts as -inf. */
+int asl_maxpool3x3s2_nhwc(const void* x, int n, int h, int w, int c, int in_halo,
+                          void* y, int out_halo, asl_stream_t stream);
+
+/* nn.MaxPool3d((kd,kh,kw), (sd,sh,sw), pad = (pd,ph,pw)) on halo'd NDHWC bf16, inputs >= 0. */
+typedef struct asl_pool3d_params {
+    int32_t n, d, h, w, c, in_halo_d, in_halo;
+    int32_t kd, kh, kw, sd, sh, sw, pd, ph, pw;
+    int32_t out_halo_d, out_halo;
+} asl_pool3d_params;
+int asl_maxpool3d_ndhwc(const asl_pool3d_params* p, const void* x, void* y, asl_stream_t stream);
+
+/* x.mean((2,3)) per frame: halo'd NHWC bf16 [n][h+2*halo][w+2*halo][c] -> fp32 [n][c] (and, if
+ * y_bf16 != NULL, the same values rounded to bf16 with row pitch ld_bf16, as GEMM input).
+ * c/8 must be a power of two below 256 or a multiple of 256. */
+int asl_avgpool_nhwc(const void* x, int n, int h, int w, int c, int halo,
+                     float* y_f32, void* y_bf16, int ld_bf16, asl_stream_t stream);
+
+/* y[r][c] = mean over t of x[r][t][c]  (fp32 [rows][t][c] -> fp32 [rows][c]) */
+int asl_mean_t_f32(const float* x, int rows, int t, int c, float* y, asl_stream_t stream);
+
+/* nn.Linear(f, c) for a handful of rows, all fp32: y[m][c] = x[m][:] . w[c][:] + b[c]. */
+int asl_head_f32(const float* x, int m, int f, const float* w, const float* b, int c,
+                 float* y, asl_stream_t stream);
+
+/* F.softmax(logits, -1).topk(k): logits fp32 [m][c] -> idx int64 [m][k], prob fp32 [m][k];
+ * k <= 16.  Ties resolve to the lower class index. */
+int asl_softmax_topk(const float* logits, int m, int c, int k, int64_t* idx, float* prob,
+                     asl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASL_HIP_H */

@@ -1,0 +1,387 @@
+"""CPU oracle for the video-ASL clip -> logits path.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED BY THE REFERENCE: the reference snapshot holds no source code, no
+tests and no golden vectors (/root/reference/README.md:1 is a bare title,
+/root/reference/.gitignore:1-5 only names ignored paths), so there is nothing of the
+reference's to pin this oracle against.  It is a build-owned restatement of the
+"PyTorch CPU eager" stack that BASELINE.json's configs name: stock ``torch.nn`` modules,
+fp32, ``eval()``, ``torch.no_grad()``.  What pins it instead:
+  * ``oracle/np_restatement.py`` re-derives every op family used here in plain numpy
+    (conv, batch-norm, pools, bilinear resize, LSTM cell, attention, layer-norm) and
+    ``tests/test_oracle.py`` checks the two against each other;
+  * ``tests/golden/*.npz`` freezes seeded inputs and logits produced by this file (the
+    generating script is ``tests/golden/make_golden.py``).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product package never does.
+
+Model families (one per BASELINE.json config):
+  tiny                    8-frame 112x112 clip -> 2-layer CNN -> mean over T -> Linear
+  resnet18_mean           ResNet-18 per frame -> mean over T -> Linear
+  i3d                     Inception-I3D style 3-D conv net
+  resnet50_bilstm         ResNet-50 per frame -> 2-layer BiLSTM -> mean over T -> Linear
+  twostream_transformer   ResNet-18 + hand-keypoint MLP -> 4-layer transformer -> Linear(2000)
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+@dataclass(frozen=True)
+class OracleSpec:
+    name: str
+    frames: int          # T the config is quoted at
+    size: int            # S (square input)
+    num_classes: int
+    batch: int           # B the config is quoted at
+
+
+SPECS = {
+    "tiny": OracleSpec("tiny", 8, 112, 100, 2),
+    "resnet18_mean": OracleSpec("resnet18_mean", 32, 224, 100, 8),
+    "i3d": OracleSpec("i3d", 64, 224, 100, 16),
+    "resnet50_bilstm": OracleSpec("resnet50_bilstm", 64, 224, 100, 16),
+    "twostream_transformer": OracleSpec("twostream_transformer", 128, 224, 2000, 8),
+}
+
+
+# --------------------------------------------------------------------------------------
+# 2-D backbones (written out from torch.nn; torchvision is not installed)
+# --------------------------------------------------------------------------------------
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or cin != planes:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return F.relu(y + idt)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)   # stride on the 3x3 ("v1.5")
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if stride != 1 or cin != planes * 4:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return F.relu(y + idt)
+
+
+class ResNet(nn.Module):
+    """ResNet trunk up to the global average pool; returns [N, feat_dim]."""
+
+    def __init__(self, block, layers):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for i, (planes, n) in enumerate(zip((64, 128, 256, 512), layers)):
+            blocks = []
+            for j in range(n):
+                stride = 2 if (i > 0 and j == 0) else 1
+                blocks.append(block(cin, planes, stride))
+                cin = planes * block.expansion
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        self.feat_dim = cin
+
+    def forward(self, x):
+        x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return x.mean((2, 3))
+
+
+def resnet18():
+    return ResNet(BasicBlock, (2, 2, 2, 2))
+
+
+def resnet50():
+    return ResNet(Bottleneck, (3, 4, 6, 3))
+
+
+class TinyBackbone(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 32, 3, 2, 1)
+        self.conv2 = nn.Conv2d(32, 64, 3, 2, 1)
+        self.feat_dim = 64
+
+    def forward(self, x):
+        x = F.relu(self.conv2(F.relu(self.conv1(x))))
+        return x.mean((2, 3))
+
+
+# --------------------------------------------------------------------------------------
+# I3D-style 3-D backbone (symmetric k//2 padding instead of TF-SAME)
+# --------------------------------------------------------------------------------------
+class Unit3D(nn.Module):
+    def __init__(self, cin, cout, k, stride=1):
+        super().__init__()
+        k3 = (k, k, k) if isinstance(k, int) else k
+        self.conv = nn.Conv3d(cin, cout, k3, stride, tuple(s // 2 for s in k3), bias=False)
+        self.bn = nn.BatchNorm3d(cout, eps=1e-3)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)))
+
+
+class Mixed(nn.Module):
+    def __init__(self, cin, w):
+        super().__init__()
+        self.b0 = Unit3D(cin, w[0], 1)
+        self.b1a = Unit3D(cin, w[1], 1)
+        self.b1b = Unit3D(w[1], w[2], 3)
+        self.b2a = Unit3D(cin, w[3], 1)
+        self.b2b = Unit3D(w[3], w[4], 3)
+        self.b3pool = nn.MaxPool3d(3, 1, 1)
+        self.b3b = Unit3D(cin, w[5], 1)
+        self.cout = w[0] + w[2] + w[4] + w[5]
+
+    def forward(self, x):
+        return torch.cat([self.b0(x), self.b1b(self.b1a(x)), self.b2b(self.b2a(x)),
+                          self.b3b(self.b3pool(x))], 1)
+
+
+I3D_MIXED = (
+    ("mixed_3b", (64, 96, 128, 16, 32, 32)), ("mixed_3c", (128, 128, 192, 32, 96, 64)),
+    ("pool_4a", None),
+    ("mixed_4b", (192, 96, 208, 16, 48, 64)), ("mixed_4c", (160, 112, 224, 24, 64, 64)),
+    ("mixed_4d", (128, 128, 256, 24, 64, 64)), ("mixed_4e", (112, 144, 288, 32, 64, 64)),
+    ("mixed_4f", (256, 160, 320, 32, 128, 128)),
+    ("pool_5a", None),
+    ("mixed_5b", (256, 160, 320, 32, 128, 128)), ("mixed_5c", (384, 192, 384, 48, 128, 128)),
+)
+
+
+class I3D(nn.Module):
+    """clips [B,3,T,H,W] -> logits [B,C] (mean over the remaining time axis)."""
+
+    def __init__(self, num_classes):
+        super().__init__()
+        self.conv_1a = Unit3D(3, 64, 7, 2)
+        self.pool_2a = nn.MaxPool3d((1, 3, 3), (1, 2, 2), (0, 1, 1))
+        self.conv_2b = Unit3D(64, 64, 1)
+        self.conv_2c = Unit3D(64, 192, 3)
+        self.pool_3a = nn.MaxPool3d((1, 3, 3), (1, 2, 2), (0, 1, 1))
+        cin = 192
+        names = []
+        for name, w in I3D_MIXED:
+            if name == "pool_4a":
+                mod = nn.MaxPool3d(3, 2, 1)
+            elif name == "pool_5a":
+                mod = nn.MaxPool3d(2, 2, 0)
+            else:
+                mod = Mixed(cin, w)
+                cin = mod.cout
+            setattr(self, name, mod)
+            names.append(name)
+        self._names = names
+        self.logits = nn.Conv3d(cin, num_classes, 1, bias=True)
+
+    def forward(self, x):
+        x = self.pool_3a(self.conv_2c(self.conv_2b(self.pool_2a(self.conv_1a(x)))))
+        for n in self._names:
+            x = getattr(self, n)(x)
+        x = F.avg_pool3d(x, (min(2, x.shape[2]), x.shape[3], x.shape[4]), 1)
+        x = self.logits(x)                      # [B,C,T',1,1]
+        return x.flatten(2).mean(2)
+
+
+# --------------------------------------------------------------------------------------
+# clip models
+# --------------------------------------------------------------------------------------
+def sinusoid_posenc(T, d):
+    pos = torch.arange(T, dtype=torch.float32)[:, None]
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * (-math.log(10000.0) / d))
+    pe = torch.zeros(T, d)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+class ClipModel(nn.Module):
+    """forward(clips [B,T,3,S,S] float32, keypoints [B,T,21,2] | None) -> logits [B,C] float32."""
+
+    def __init__(self, name, num_classes):
+        super().__init__()
+        self.name = name
+        self.num_classes = num_classes
+        if name == "tiny":
+            self.backbone = TinyBackbone()
+            self.fc = nn.Linear(64, num_classes)
+        elif name == "resnet18_mean":
+            self.backbone = resnet18()
+            self.fc = nn.Linear(512, num_classes)
+        elif name == "i3d":
+            self.backbone = I3D(num_classes)
+        elif name == "resnet50_bilstm":
+            self.backbone = resnet50()
+            self.lstm = nn.LSTM(2048, 512, num_layers=2, bidirectional=True, batch_first=True)
+            self.fc = nn.Linear(1024, num_classes)
+        elif name == "twostream_transformer":
+            self.backbone = resnet18()
+            self.kp_mlp = nn.Sequential(nn.Linear(42, 128), nn.ReLU(), nn.Linear(128, 128))
+            self.fuse = nn.Linear(640, 512)
+            layer = nn.TransformerEncoderLayer(512, 8, 2048, dropout=0.0, activation="relu",
+                                               batch_first=True, norm_first=False)
+            self.encoder = nn.TransformerEncoder(layer, 4, enable_nested_tensor=False)
+            self.fc = nn.Linear(512, num_classes)
+        else:
+            raise ValueError(name)
+
+    def frame_features(self, clips):
+        B, T = clips.shape[:2]
+        return self.backbone(clips.flatten(0, 1)).view(B, T, -1)
+
+    def forward(self, clips, keypoints=None):
+        if self.name == "i3d":
+            return self.backbone(clips.permute(0, 2, 1, 3, 4))
+        f = self.frame_features(clips)
+        if self.name in ("tiny", "resnet18_mean"):
+            return self.fc(f.mean(1))
+        if self.name == "resnet50_bilstm":
+            y, _ = self.lstm(f)
+            return self.fc(y.mean(1))
+        B, T = f.shape[:2]
+        k = self.kp_mlp(keypoints.reshape(B, T, -1))
+        x = self.fuse(torch.cat([f, k], -1))
+        # math path of nn.TransformerEncoder kept on the eager (non-fused) kernels
+        x = x + sinusoid_posenc(T, x.shape[-1])
+        x = self.encoder(x)
+        return self.fc(x.mean(1))
+
+
+def bf16_round_(t):
+    t.copy_(t.to(torch.bfloat16).to(torch.float32))
+    return t
+
+
+@torch.no_grad()
+def init_params(model, seed):
+    """Seeded init with non-trivial BN statistics; every float ends up bf16-representable."""
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+            fan_out = m.weight.shape[0] * m.weight[0, 0].numel()
+            m.weight.normal_(0.0, math.sqrt(2.0 / fan_out), generator=g)
+            if m.bias is not None:
+                m.bias.normal_(0.0, 0.1, generator=g)
+        elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.weight.uniform_(0.5, 1.5, generator=g)
+            m.bias.normal_(0.0, 0.1, generator=g)
+            m.running_mean.normal_(0.0, 0.1, generator=g)
+            m.running_var.uniform_(0.5, 1.5, generator=g)
+    # Linear / LSTM / MultiheadAttention / LayerNorm: PyTorch's default scale, drawn from g
+    for n, p in model.named_parameters():
+        mod = n.rsplit(".", 1)[0]
+        owner = model.get_submodule(mod)
+        if isinstance(owner, (nn.Conv2d, nn.Conv3d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            continue
+        if isinstance(owner, nn.LayerNorm):
+            if n.endswith("weight"):
+                p.uniform_(0.5, 1.5, generator=g)
+            else:
+                p.normal_(0.0, 0.1, generator=g)
+        elif isinstance(owner, nn.LSTM):
+            k = 1.0 / math.sqrt(owner.hidden_size)
+            p.uniform_(-k, k, generator=g)
+        elif p.dim() >= 2:
+            k = 1.0 / math.sqrt(p.shape[1])
+            p.uniform_(-k, k, generator=g)
+        else:
+            p.uniform_(-0.05, 0.05, generator=g)
+    for p in model.parameters():
+        bf16_round_(p)
+    for b in model.buffers():
+        if b.dtype.is_floating_point:
+            bf16_round_(b)
+    return model
+
+
+def build(name, num_classes=None, seed=0):
+    spec = SPECS[name]
+    torch.backends.mha.set_fastpath_enabled(False)
+    m = ClipModel(name, num_classes or spec.num_classes)
+    init_params(m, seed)
+    return m.eval()
+
+
+# --------------------------------------------------------------------------------------
+# preprocess + classify_clip
+# --------------------------------------------------------------------------------------
+@torch.no_grad()
+def preprocess(frames_u8, size):
+    """uint8 [B,T,H0,W0,3] -> float32 [B,T,3,S,S]: bilinear resize (half-pixel centres, no
+    antialias), /255, ImageNet mean/std."""
+    B, T, H0, W0, _ = frames_u8.shape
+    x = frames_u8.flatten(0, 1).permute(0, 3, 1, 2).to(torch.float32)
+    x = F.interpolate(x, size=(size, size), mode="bilinear", align_corners=False, antialias=False)
+    mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    x = (x / 255.0 - mean) / std
+    return x.view(B, T, 3, size, size)
+
+
+@torch.no_grad()
+def classify_clip(model, frames_u8, keypoints=None, topk=5, size=224):
+    if frames_u8.dim() == 4:
+        frames_u8 = frames_u8[None]
+        if keypoints is not None and keypoints.dim() == 3:
+            keypoints = keypoints[None]
+    logits = model(preprocess(frames_u8, size), keypoints)
+    prob = F.softmax(logits, -1)
+    p, i = prob.topk(topk, -1)
+    return i, p
+
+
+# --------------------------------------------------------------------------------------
+# seeded synthetic inputs (values bf16-representable so both sides hold identical numbers)
+# --------------------------------------------------------------------------------------
+def make_clips(B, T, S, seed=0):
+    g = torch.Generator().manual_seed(1000 + seed)
+    return bf16_round_(torch.randn(B, T, 3, S, S, generator=g))
+
+
+def make_frames(B, T, H0=240, W0=320, seed=0):
+    g = torch.Generator().manual_seed(2000 + seed)
+    return torch.randint(0, 256, (B, T, H0, W0, 3), generator=g, dtype=torch.uint8)
+
+
+def make_keypoints(B, T, seed=0):
+    g = torch.Generator().manual_seed(3000 + seed)
+    return bf16_round_(torch.rand(B, T, 21, 2, generator=g))

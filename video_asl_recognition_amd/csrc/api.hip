@@ -1,0 +1,128 @@
+// Shape-level entry points of libaslhip.so: each fills the gather-GEMM's addressing from a
+// friendlier description (conv2d / packed stem / conv3d / linear) and forwards to it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "asl_hip.h"
+
+extern "C" int asl_version(void) { return 100; }
+
+extern "C" const char* asl_strerror(int rc) {
+    switch (rc) {
+        case ASL_OK: return "ok";
+        case ASL_EINVAL: return "asl: invalid argument (shape, alignment or bounds)";
+        case ASL_ENOTSUP: return "asl: no kernel variant for this request";
+        default: return rc > 0 ? hipGetErrorString((hipError_t)rc) : "asl: unknown error";
+    }
+}
+
+extern "C" int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, const void* w, const float* scale,
+                                    const float* bias, const void* res, void* y, asl_stream_t stream) {
+    if (!p) return ASL_EINVAL;
+    if (p->n <= 0 || p->h <= 0 || p->w <= 0 || p->cin <= 0 || (p->cin & 31) || p->cout <= 0) return ASL_EINVAL;
+    if (p->kh <= 0 || p->kw <= 0 || p->stride <= 0 || p->pad < 0 || p->in_halo < p->pad) return ASL_EINVAL;
+    if (p->out_halo < 0 || p->out_coff < 0 || p->out_coff + p->cout > p->out_ctot) return ASL_EINVAL;
+    const int oh = (p->h + 2 * p->pad - p->kh) / p->stride + 1;
+    const int ow = (p->w + 2 * p->pad - p->kw) / p->stride + 1;
+    if (oh <= 0 || ow <= 0) return ASL_EINVAL;
+    const int wp = p->w + 2 * p->in_halo, hp = p->h + 2 * p->in_halo;
+    asl_gemm_params g = {};
+    g.nb = p->n; g.od = 1; g.oh = oh; g.ow = ow; g.cout = p->cout;
+    g.kd = 1; g.kh = p->kh; g.kw = p->kw; g.ck = p->cin;
+    g.tap_sd = 0; g.tap_sh = wp * p->cin; g.tap_sw = p->cin;
+    g.in.sn = (int64_t)hp * wp * p->cin; g.in.sd = 0;
+    g.in.sh = p->stride * wp * p->cin; g.in.sw = p->stride * p->cin;
+    g.in.off0 = ((p->in_halo - p->pad) * wp + (p->in_halo - p->pad)) * p->cin;
+    const int owp = ow + 2 * p->out_halo, ohp = oh + 2 * p->out_halo;
+    g.out.sn = (int64_t)ohp * owp * p->out_ctot; g.out.sd = 0;
+    g.out.sh = owp * p->out_ctot; g.out.sw = p->out_ctot;
+    g.out.off0 = (p->out_halo * owp + p->out_halo) * p->out_ctot + p->out_coff;
+    g.y_elems = (int64_t)p->n * g.out.sn;
+    if (res) {
+        if (p->res_halo < 0 || p->res_coff < 0 || p->res_coff + p->cout > p->res_ctot) return ASL_EINVAL;
+        const int rwp = ow + 2 * p->res_halo, rhp = oh + 2 * p->res_halo;
+        g.res.sn = (int64_t)rhp * rwp * p->res_ctot; g.res.sd = 0;
+        g.res.sh = rwp * p->res_ctot; g.res.sw = p->res_ctot;
+        g.res.off0 = (p->res_halo * rwp + p->res_halo) * p->res_ctot + p->res_coff;
+        g.res_elems = (int64_t)p->n * g.res.sn;
+    }
+    g.relu = p->relu; g.out_f32 = 0; g.w_rows = p->w_rows;
+    g.x_elems = (int64_t)p->n * g.in.sn;
+    return asl_gather_gemm_bf16(&g, x, w, scale, bias, res, y, stream);
+}
+
+extern "C" int asl_stem7x7_bf16(const asl_stem_params* p, const void* x, const void* w, const float* scale,
+                                const float* bias, void* y, asl_stream_t stream) {
+    if (!p) return ASL_EINVAL;
+    if (p->n <= 0 || p->h <= 0 || p->w <= 0 || (p->h & 1) || (p->w & 1) || p->cout <= 0 || p->out_halo < 0)
+        return ASL_EINVAL;
+    const int oh = p->h / 2, ow = p->w / 2;           // (h + 6 - 7) / 2 + 1 for even h
+    const int wp = p->w + 6, hp = p->h + 6;
+    asl_gemm_params g = {};
+    g.nb = p->n; g.od = 1; g.oh = oh; g.ow = ow; g.cout = p->cout;
+    // one "tap" per filter row: 8 pixels x 4 channels = 32 contiguous elements (pixel 7, channel 3
+    // carry zero weights)
+    g.kd = 1; g.kh = 7; g.kw = 1; g.ck = 32;
+    g.tap_sd = 0; g.tap_sh = wp * 4; g.tap_sw = 0;
+    g.in.sn = (int64_t)hp * wp * 4; g.in.sd = 0; g.in.sh = 2 * wp * 4; g.in.sw = 2 * 4; g.in.off0 = 0;
+    const int owp = ow + 2 * p->out_halo, ohp = oh + 2 * p->out_halo;
+    g.out.sn = (int64_t)ohp * owp * p->cout; g.out.sd = 0; g.out.sh = owp * p->cout; g.out.sw = p->cout;
+    g.out.off0 = (p->out_halo * owp + p->out_halo) * p->cout;
+    g.relu = 1; g.out_f32 = 0; g.w_rows = p->w_rows;
+    // the last pixel's 8-pixel window ends exactly at the right halo edge; the packed tensor
+    // is followed by nothing, so the window of the very last row needs no slack either
+    g.x_elems = (int64_t)p->n * g.in.sn;
+    g.y_elems = (int64_t)p->n * g.out.sn;
+    return asl_gather_gemm_bf16(&g, x, w, scale, bias, nullptr, y, stream);
+}
+
+extern "C" int asl_conv3d_ndhwc_bf16(const asl_conv3d_params* p, const void* x, const void* w, const float* scale,
+                                     const float* bias, void* y, asl_stream_t stream) {
+    if (!p) return ASL_EINVAL;
+    if (p->n <= 0 || p->d <= 0 || p->h <= 0 || p->w <= 0 || p->cin <= 0 || (p->cin & 31) || p->cout <= 0)
+        return ASL_EINVAL;
+    if (p->kd <= 0 || p->kh <= 0 || p->kw <= 0 || p->stride <= 0 || p->stride_d <= 0) return ASL_EINVAL;
+    if (p->pad < 0 || p->pad_d < 0 || p->in_halo < p->pad || p->in_halo_d < p->pad_d) return ASL_EINVAL;
+    if (p->out_halo < 0 || p->out_halo_d < 0 || p->out_coff < 0 || p->out_coff + p->cout > p->out_ctot)
+        return ASL_EINVAL;
+    const int od = (p->d + 2 * p->pad_d - p->kd) / p->stride_d + 1;
+    const int oh = (p->h + 2 * p->pad - p->kh) / p->stride + 1;
+    const int ow = (p->w + 2 * p->pad - p->kw) / p->stride + 1;
+    if (od <= 0 || oh <= 0 || ow <= 0) return ASL_EINVAL;
+    const int wp = p->w + 2 * p->in_halo, hp = p->h + 2 * p->in_halo, dp = p->d + 2 * p->in_halo_d;
+    asl_gemm_params g = {};
+    g.nb = p->n; g.od = od; g.oh = oh; g.ow = ow; g.cout = p->cout;
+    g.kd = p->kd; g.kh = p->kh; g.kw = p->kw; g.ck = p->cin;
+    const int64_t plane = (int64_t)hp * wp * p->cin;
+    if (plane * p->stride_d > 0x7fffffffLL) return ASL_EINVAL;
+    g.tap_sd = (int32_t)plane; g.tap_sh = wp * p->cin; g.tap_sw = p->cin;
+    g.in.sn = plane * dp; g.in.sd = (int32_t)(p->stride_d * plane);
+    g.in.sh = p->stride * wp * p->cin; g.in.sw = p->stride * p->cin;
+    g.in.off0 = (int32_t)((p->in_halo_d - p->pad_d) * plane) +
+                ((p->in_halo - p->pad) * wp + (p->in_halo - p->pad)) * p->cin;
+    const int owp = ow + 2 * p->out_halo, ohp = oh + 2 * p->out_halo, odp = od + 2 * p->out_halo_d;
+    const int64_t oplane = (int64_t)ohp * owp * p->out_ctot;
+    if (oplane > 0x7fffffffLL) return ASL_EINVAL;
+    g.out.sn = oplane * odp; g.out.sd = (int32_t)oplane; g.out.sh = owp * p->out_ctot; g.out.sw = p->out_ctot;
+    g.out.off0 = (int32_t)(p->out_halo_d * oplane) + (p->out_halo * owp + p->out_halo) * p->out_ctot + p->out_coff;
+    g.relu = p->relu; g.out_f32 = 0; g.w_rows = p->w_rows;
+    g.x_elems = (int64_t)p->n * g.in.sn;
+    g.y_elems = (int64_t)p->n * g.out.sn;
+    return asl_gather_gemm_bf16(&g, x, w, scale, bias, nullptr, y, stream);
+}
+
+extern "C" int asl_linear_bf16(const asl_linear_params* p, const void* x, const void* w, const float* scale,
+                               const float* bias, const void* res, void* y, asl_stream_t stream) {
+    if (!p) return ASL_EINVAL;
+    if (p->m <= 0 || p->n <= 0 || p->k <= 0 || (p->k & 31) || p->ldx < p->k || p->ldy < p->n) return ASL_EINVAL;
+    if (res && p->ldres < p->n) return ASL_EINVAL;
+    asl_gemm_params g = {};
+    g.nb = p->m; g.od = g.oh = g.ow = 1; g.cout = p->n;
+    g.kd = g.kh = g.kw = 1; g.ck = p->k;
+    g.in.sn = p->ldx; g.out.sn = p->ldy; g.res.sn = p->ldres;
+    g.relu = p->relu; g.out_f32 = p->out_f32; g.w_rows = p->w_rows;
+    g.x_elems = (int64_t)(p->m - 1) * p->ldx + p->k;
+    g.y_elems = (int64_t)(p->m - 1) * p->ldy + p->n;
+    g.res_elems = (int64_t)(p->m - 1) * p->ldres + p->n;
+    return asl_gather_gemm_bf16(&g, x, w, scale, bias, res, y, stream);
+}

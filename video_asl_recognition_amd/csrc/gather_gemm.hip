@@ -1,0 +1,344 @@
+// Gather-GEMM for gfx950: convolution (2-D, 3-D, the packed 7x7 stem) and nn.Linear as one
+// bf16 MFMA kernel.  Output row m is an output pixel; its K axis is "taps x contiguous
+// channels", every tap a constant element offset from the pixel's first input element, so
+// the zero halo of the activation layout supplies the padding and the activation operand
+// is fetched by LDS-DMA (buffer_load ... lds) with one fixed per-lane offset for the whole
+// K loop and one scalar offset per K step.
+//
+// MFMA orientation: the weight tile is the A operand (rows = output channels) and the
+// pixel tile the B operand (columns = pixels), so each lane ends up holding 4 CONSECUTIVE
+// channels of one pixel per 16x16 tile and the epilogue stores channels-last without a
+// transpose.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "asl_hip.h"
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+    const char* x;
+    const char* w;
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    int M, N;
+    int OHW, ODHW, OW;
+    long long in_sn, out_sn, res_sn;
+    int in_sd, in_sh, in_sw, in_off0;
+    int out_sd, out_sh, out_sw, out_off0;
+    int res_sd, res_sh, res_sw, res_off0;
+    int KH, KW, ksteps_per_tap, ntaps;
+    int tap_sd, tap_sh, tap_sw;
+    int wk;                      // packed K (elements per weight row)
+    long long x_bytes, w_bytes;
+    int relu, out_f32;
+    int tiles_m, tiles_n;
+};
+
+// LDS chunk swizzle: slot (row, c') of a staged tile holds 16-byte chunk c' ^ swz(row) of that
+// row.  Chosen so that a 16-row x 16-byte fragment read (ds_read_b128) is bank-conflict
+// free under the instruction's own lane grouping: 128-byte rows need the 8 chunk slots
+// of rows 2i, 2i+1 rotated per row pair, 64-byte rows need rows 8-15 flipped against 0-7.
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+    if constexpr (BK == 64) return (row >> 1) & 7;
+    else return (row & 8) ? 3 : 0;
+}
+
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+__global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmArgs a) {
+    constexpr int NW = WGM * WGN;
+    constexpr int RB = BK * 2;        // bytes per staged row
+    constexpr int CPR = RB / 16;      // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;     // rows per wave-wide LDS-DMA instruction (1 KiB)
+    constexpr int X_BYTES = BM * RB, W_BYTES = BN * RB;
+    constexpr int X_PW = X_BYTES / 1024 / NW, W_PW = W_BYTES / 1024 / NW;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile: pixels x channels
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+    constexpr int KK = BK / 32;
+    static_assert(X_PW >= 1 && W_PW >= 1, "tile too small for the wave count");
+    static_assert(X_PW * NW * 1024 == X_BYTES && W_PW * NW * 1024 == W_BYTES, "tile/wave mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BUF = X_BYTES + W_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // blocks that share an XCD (same blockIdx % 8) get neighbouring tiles: consecutive
+    // logical ids walk the channel tiles of one pixel tile, then the next pixel tile.
+    int lbid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lbid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = lbid % a.tiles_n, tm = lbid / a.tiles_n;
+    const int m0 = tm * BM;
+    const int n0img = m0 / a.ODHW;      // first image this tile touches (block-uniform)
+
+    // ---- LDS-DMA source offsets: fixed per lane for the whole K loop --------------------
+    const char* xbase = a.x + 2 * (long long)n0img * a.in_sn;
+    long long xrem = a.x_bytes - 2 * (long long)n0img * a.in_sn;
+    const unsigned xrec = (unsigned)(xrem > 0x7fffffffLL ? 0x7fffffffLL : xrem);
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, xrec, 0x00020000);
+    const char* wbase = a.w + 2 * (long long)(tn * BN) * a.wk;
+    const unsigned wrec = (unsigned)(a.w_bytes - 2 * (long long)(tn * BN) * a.wk);
+    __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wrec, 0x00020000);
+
+    unsigned xvoff[X_PW], wvoff[W_PW];
+#pragma unroll
+    for (int i = 0; i < X_PW; ++i) {
+        const int row = (wave * X_PW + i) * RPI + lane / CPR;
+        const int chunk = (lane % CPR) ^ swz<BK>(row);
+        const int m = m0 + row;
+        if (m < a.M) {
+            const int n = m / a.ODHW, r1 = m - n * a.ODHW;
+            const int d = r1 / a.OHW, r2 = r1 - d * a.OHW;
+            const int h = r2 / a.OW, w_ = r2 - h * a.OW;
+            const long long e = (long long)(n - n0img) * a.in_sn + (long long)d * a.in_sd +
+                                (long long)h * a.in_sh + (long long)w_ * a.in_sw + a.in_off0;
+            xvoff[i] = (unsigned)(2 * e + 16 * chunk);
+        } else {
+            xvoff[i] = 0x80000000u;     // beyond num_records: the DMA writes zeros
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < W_PW; ++i) {
+        const int row = (wave * W_PW + i) * RPI + lane / CPR;
+        const int chunk = (lane % CPR) ^ swz<BK>(row);
+        wvoff[i] = (unsigned)(2 * row * a.wk + 16 * chunk);
+    }
+
+    // ---- K-step state (scalar): tap (d,r,q) and channel chunk -----------------------------
+    int st_c = 0, st_q = 0, st_r = 0, st_d = 0;
+    unsigned st_xoff = 0, st_woff = 0;      // byte offsets for the NEXT stage() call
+    auto stage = [&](int buf) {
+        char* lx = smem + buf * BUF + wave * (X_PW * 1024);
+        char* lw = smem + buf * BUF + X_BYTES + wave * (W_PW * 1024);
+        // the offsets are wave-uniform by construction; say so, or hipcc wraps every DMA in a
+        // readfirstlane loop
+        const unsigned xo = __builtin_amdgcn_readfirstlane(st_xoff);
+        const unsigned wo = __builtin_amdgcn_readfirstlane(st_woff);
+#pragma unroll
+        for (int i = 0; i < X_PW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(lx + i * 1024),
+                                                     16, xvoff[i], xo, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_PW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(lw + i * 1024),
+                                                     16, wvoff[i], wo, 0, 0);
+        // advance to the next K step
+        st_woff += RB;
+        if (++st_c == a.ksteps_per_tap) {
+            st_c = 0;
+            if (++st_q == a.KW) {
+                st_q = 0;
+                if (++st_r == a.KH) { st_r = 0; ++st_d; }
+            }
+            st_xoff = 2u * (unsigned)(st_d * a.tap_sd + st_r * a.tap_sh + st_q * a.tap_sw);
+        } else {
+            st_xoff += RB;
+        }
+    };
+
+    // ---- fragment read offsets ----------------------------------------------------------
+    const int fr = lane & 15, fq = lane >> 4;
+    int xrd[FM][KK], wrd[FN][KK];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int row = wm * WTM + i * 16 + fr;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) xrd[i][kk] = row * RB + (((kk * 4 + fq) ^ swz<BK>(row)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int row = wn * WTN + i * 16 + fr;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            wrd[i][kk] = X_BYTES + row * RB + (((kk * 4 + fq) ^ swz<BK>(row)) << 4);
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = a.ntaps * a.ksteps_per_tap;
+    stage(0);
+    wait_vm0();
+    __syncthreads();
+    int buf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) stage(buf ^ 1);
+        const char* base = smem + buf * BUF;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            bf16x8 xf[FM], wf[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) xf[i] = *(const bf16x8*)(base + xrd[i][kk]);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(base + wrd[j][kk]);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+        wait_vm0();
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue: lane holds channels ch..ch+3 of pixel (lane & 15) per tile -----------------
+    const int chb = tn * BN + wn * WTN + fq * 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + fr;
+        if (m >= a.M) continue;
+        const int n = m / a.ODHW, r1 = m - n * a.ODHW;
+        const int d = r1 / a.OHW, r2 = r1 - d * a.OHW;
+        const int h = r2 / a.OW, w_ = r2 - h * a.OW;
+        const long long oe = (long long)n * a.out_sn + (long long)d * a.out_sd + (long long)h * a.out_sh +
+                             (long long)w_ * a.out_sw + a.out_off0;
+        long long re = 0;
+        if (a.res)
+            re = (long long)n * a.res_sn + (long long)d * a.res_sd + (long long)h * a.res_sh +
+                 (long long)w_ * a.res_sw + a.res_off0;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int ch = chb + j * 16;
+            if (ch >= a.N) continue;
+            f32x4 v = acc[i][j];
+            if (ch + 3 < a.N) {
+                if (a.scale) {
+                    const f32x4 s4 = *(const f32x4*)(a.scale + ch);
+                    v *= s4;
+                }
+                if (a.bias) {
+                    const f32x4 b4 = *(const f32x4*)(a.bias + ch);
+                    v += b4;
+                }
+                if (a.res) {
+                    const bf16x4 r4 = *(const bf16x4*)(a.res + 2 * (re + ch));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bf16_to_f32(r4[e]);
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.out_f32) {
+                    *(f32x4*)(a.y + 4 * (oe + ch)) = v;
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[e]);
+                    *(bf16x4*)(a.y + 2 * (oe + ch)) = o;
+                }
+            } else {
+                for (int e = 0; e < 4 && ch + e < a.N; ++e) {
+                    float t = v[e];
+                    if (a.scale) t *= a.scale[ch + e];
+                    if (a.bias) t += a.bias[ch + e];
+                    if (a.res) t += bf16_to_f32(*(const short*)(a.res + 2 * (re + ch + e)));
+                    if (a.relu) t = fmaxf(t, 0.f);
+                    if (a.out_f32) *(float*)(a.y + 4 * (oe + ch + e)) = t;
+                    else *(short*)(a.y + 2 * (oe + ch + e)) = f32_to_bf16(t);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+int launch(const GemmArgs& a, hipStream_t stream) {
+    constexpr int lds = 2 * (BM + BN) * BK * 2;
+    static_assert(lds <= 65536, "tiles above 64 KiB of LDS need hipFuncSetAttribute");
+    auto kern = gather_gemm_kernel<BM, BN, BK, WGM, WGN>;
+    GemmArgs b = a;
+    b.tiles_m = (a.M + BM - 1) / BM;
+    b.tiles_n = (a.N + BN - 1) / BN;
+    const long long nblk = (long long)b.tiles_m * b.tiles_n;
+    if (nblk > 0x7fffffffLL) return ASL_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WGM * WGN * 64), lds, stream, b);
+    return (int)hipGetLastError();
+}
+
+// largest element offset (exclusive) a geom can reach for the given output grid
+long long geom_extent(const asl_geom& g, int nb, int od, int oh, int ow) {
+    return (long long)(nb - 1) * g.sn + (long long)(od - 1) * g.sd + (long long)(oh - 1) * g.sh +
+           (long long)(ow - 1) * g.sw + g.off0;
+}
+
+bool geom_nonneg(const asl_geom& g) { return g.sn >= 0 && g.sd >= 0 && g.sh >= 0 && g.sw >= 0 && g.off0 >= 0; }
+
+}  // namespace
+
+extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, const void* w, const float* scale,
+                                    const float* bias, const void* res, void* y, asl_stream_t stream) {
+    if (!p || !x || !w || !y) return ASL_EINVAL;
+    if (p->nb <= 0 || p->od <= 0 || p->oh <= 0 || p->ow <= 0 || p->cout <= 0) return ASL_EINVAL;
+    if (p->kd <= 0 || p->kh <= 0 || p->kw <= 0 || p->ck <= 0 || (p->ck & 31)) return ASL_EINVAL;
+    if (p->tap_sd < 0 || p->tap_sh < 0 || p->tap_sw < 0) return ASL_EINVAL;
+    if (!geom_nonneg(p->in) || !geom_nonneg(p->out) || (res && !geom_nonneg(p->res))) return ASL_EINVAL;
+    const long long M = (long long)p->nb * p->od * p->oh * p->ow;
+    if (M > 0x7fffffffLL) return ASL_EINVAL;
+    const long long wk = (long long)p->kd * p->kh * p->kw * p->ck;
+    if (p->w_rows < p->cout || (p->w_rows & 127) || wk * p->w_rows * 2 > 0x7fffffffLL) return ASL_EINVAL;
+    // 16-byte alignment of every LDS-DMA source and 8-byte alignment of epilogue vectors
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)res & 7)) return ASL_EINVAL;
+    if (((uintptr_t)scale & 15) || ((uintptr_t)bias & 15)) return ASL_EINVAL;
+    if ((p->in.sn & 7) || (p->in.sd & 7) || (p->in.sh & 7) || (p->in.sw & 7) || (p->in.off0 & 7)) return ASL_EINVAL;
+    if ((p->tap_sd & 7) || (p->tap_sh & 7) || (p->tap_sw & 7)) return ASL_EINVAL;
+    if ((p->out.sn & 3) || (p->out.sd & 3) || (p->out.sh & 3) || (p->out.sw & 3) || (p->out.off0 & 3)) return ASL_EINVAL;
+    if (res && ((p->res.sn & 3) || (p->res.sd & 3) || (p->res.sh & 3) || (p->res.sw & 3) || (p->res.off0 & 3)))
+        return ASL_EINVAL;
+    // bounds: last input element read, last output / residual element touched
+    const long long tap_ext = (long long)(p->kd - 1) * p->tap_sd + (long long)(p->kh - 1) * p->tap_sh +
+                              (long long)(p->kw - 1) * p->tap_sw + p->ck;
+    if (geom_extent(p->in, p->nb, p->od, p->oh, p->ow) + tap_ext > p->x_elems) return ASL_EINVAL;
+    if (geom_extent(p->out, p->nb, p->od, p->oh, p->ow) + p->cout > p->y_elems) return ASL_EINVAL;
+    if (res && geom_extent(p->res, p->nb, p->od, p->oh, p->ow) + p->cout > p->res_elems) return ASL_EINVAL;
+    // one tile's rows must stay within a 2 GiB window of the input (32-bit DMA offsets)
+    {
+        const long long odhw = (long long)p->od * p->oh * p->ow;
+        const long long imgs = 256 / odhw + 2;
+        if (2 * (imgs * p->in.sn + (long long)p->od * p->in.sd + (long long)p->oh * p->in.sh +
+                 (long long)p->ow * p->in.sw + p->in.off0 + tap_ext) > 0x7fffffffLL)
+            return ASL_EINVAL;
+    }
+
+    GemmArgs a;
+    a.x = (const char*)x; a.w = (const char*)w; a.scale = scale; a.bias = bias;
+    a.res = (const char*)res; a.y = (char*)y;
+    a.M = (int)M; a.N = p->cout;
+    a.OW = p->ow; a.OHW = p->oh * p->ow; a.ODHW = p->od * p->oh * p->ow;
+    a.in_sn = p->in.sn; a.in_sd = p->in.sd; a.in_sh = p->in.sh; a.in_sw = p->in.sw; a.in_off0 = p->in.off0;
+    a.out_sn = p->out.sn; a.out_sd = p->out.sd; a.out_sh = p->out.sh; a.out_sw = p->out.sw; a.out_off0 = p->out.off0;
+    a.res_sn = p->res.sn; a.res_sd = p->res.sd; a.res_sh = p->res.sh; a.res_sw = p->res.sw; a.res_off0 = p->res.off0;
+    a.KH = p->kh; a.KW = p->kw; a.ntaps = p->kd * p->kh * p->kw;
+    a.tap_sd = p->tap_sd; a.tap_sh = p->tap_sh; a.tap_sw = p->tap_sw;
+    a.wk = (int)wk;
+    a.x_bytes = 2 * p->x_elems; a.w_bytes = 2 * wk * p->w_rows;
+    a.relu = p->relu; a.out_f32 = p->out_f32;
+    a.tiles_m = a.tiles_n = 0;
+
+    hipStream_t s = (hipStream_t)stream;
+    if (p->ck % 64 == 0) {
+        a.ksteps_per_tap = p->ck / 64;
+        if (p->cout <= 64) return launch<128, 64, 64, 2, 2>(a, s);
+        return launch<128, 128, 64, 2, 2>(a, s);
+    }
+    a.ksteps_per_tap = p->ck / 32;
+    if (p->cout <= 64) return launch<128, 64, 32, 2, 2>(a, s);
+    return launch<128, 128, 32, 2, 2>(a, s);
+}

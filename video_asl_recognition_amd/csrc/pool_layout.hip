@@ -1,0 +1,369 @@
+// HBM-bound layout, preprocess, pooling and head kernels for gfx950.  Every kernel moves
+// 8-16 bytes per lane with consecutive lanes on consecutive addresses.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "asl_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int kHalo0 = 3;   // halo of the packed stem input (the 7x7 stem's padding)
+
+// ---------------------------------------------------------------------------------------
+// clips [n][3][s][s] -> packed [n][s+6][s+6][4] bf16; one lane per 2 output pixels (16 B)
+// ---------------------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void pack_clips_kernel(const void* __restrict__ clips, int n, int s,
+                                                         short* __restrict__ y) {
+    const int sp = s + 2 * kHalo0;          // even: s is even
+    const int pairs_per_row = sp / 2;
+    const long long total = (long long)n * sp * pairs_per_row;
+    const long long plane = (long long)s * s;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int px = (int)(i % pairs_per_row) * 2;
+        const long long t = i / pairs_per_row;
+        const int py = (int)(t % sp);
+        const long long img = t / sp;
+        bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int yy = py - kHalo0;
+        if (yy >= 0 && yy < s) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int xx = px + k - kHalo0;
+                if (xx >= 0 && xx < s) {
+                    const long long base = img * 3 * plane + (long long)yy * s + xx;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if constexpr (F32) o[4 * k + c] = f32_to_bf16(((const float*)clips)[base + c * plane]);
+                        else o[4 * k + c] = ((const short*)clips)[base + c * plane];
+                    }
+                }
+            }
+        }
+        *(bf16x8*)(y + 8 * i) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// uint8 frames [n][h0][w0][3] -> bilinear resize -> /255 -> (x-mean)/std -> packed bf16
+// Source index and weights follow ATen's area_pixel_compute_source_index /
+// guard_index_and_lambda for align_corners=False (scale = in/out in fp32).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ frames, int n, int h0, int w0,
+                                                         int s, float m0, float m1, float m2, float i0, float i1,
+                                                         float i2, short* __restrict__ y,
+                                                         float* __restrict__ clips_f32) {
+    const int sp = s + 2 * kHalo0;
+    const long long total = (long long)n * sp * sp;
+    const float sy = (float)h0 / (float)s, sx = (float)w0 / (float)s;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {i0, i1, i2};
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int px = (int)(i % sp);
+        const long long t = i / sp;
+        const int py = (int)(t % sp);
+        const long long img = t / sp;
+        bf16x4 o = {0, 0, 0, 0};
+        const int oy = py - kHalo0, ox = px - kHalo0;
+        if (oy >= 0 && oy < s && ox >= 0 && ox < s) {
+            float fy = sy * ((float)oy + 0.5f) - 0.5f;
+            float fx = sx * ((float)ox + 0.5f) - 0.5f;
+            fy = fy < 0.f ? 0.f : fy;
+            fx = fx < 0.f ? 0.f : fx;
+            int y0 = (int)fy, x0 = (int)fx;
+            y0 = y0 < h0 - 1 ? y0 : h0 - 1;
+            x0 = x0 < w0 - 1 ? x0 : w0 - 1;
+            const int y1 = y0 + (y0 < h0 - 1 ? 1 : 0), x1 = x0 + (x0 < w0 - 1 ? 1 : 0);
+            const float ly = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            const uint8_t* f = frames + img * (long long)h0 * w0 * 3;
+            const uint8_t* p00 = f + ((long long)y0 * w0 + x0) * 3;
+            const uint8_t* p01 = f + ((long long)y0 * w0 + x1) * 3;
+            const uint8_t* p10 = f + ((long long)y1 * w0 + x0) * 3;
+            const uint8_t* p11 = f + ((long long)y1 * w0 + x1) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = hy * (hx * (float)p00[c] + lx * (float)p01[c]) +
+                                ly * (hx * (float)p10[c] + lx * (float)p11[c]);
+                const float z = (v / 255.0f - mean[c]) / sd[c];
+                o[c] = f32_to_bf16(z);
+                if (clips_f32) clips_f32[((img * 3 + c) * s + oy) * (long long)s + ox] = z;
+            }
+        }
+        *(bf16x4*)(y + 4 * i) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// max pooling over halo'd channels-last tensors; one lane per 8 channels of an output pixel
+// ---------------------------------------------------------------------------------------
+struct PoolArgs {
+    const short* x;
+    short* y;
+    int n, od, oh, ow, c8;          // c8 = channels / 8
+    int kd, kh, kw, sd, sh, sw;
+    long long in_sn, out_sn;        // element strides
+    int in_sd, in_sh, in_sw, in_off0;
+    int out_sd, out_sh, out_sw, out_off0;
+};
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
+    const long long total = (long long)a.n * a.od * a.oh * a.ow * a.c8;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % a.c8);
+        long long t = i / a.c8;
+        const int w = (int)(t % a.ow); t /= a.ow;
+        const int h = (int)(t % a.oh); t /= a.oh;
+        const int d = (int)(t % a.od);
+        const long long n = t / a.od;
+        const short* src = a.x + n * a.in_sn + (long long)d * a.sd * a.in_sd + (long long)h * a.sh * a.in_sh +
+                           (long long)w * a.sw * a.in_sw + a.in_off0 + 8 * c;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = 0.f;     // inputs are >= 0 and every window holds a real cell
+        for (int kd = 0; kd < a.kd; ++kd)
+            for (int kh = 0; kh < a.kh; ++kh)
+                for (int kw = 0; kw < a.kw; ++kw) {
+                    const bf16x8 v = *(const bf16x8*)(src + (long long)kd * a.in_sd + (long long)kh * a.in_sh +
+                                                      (long long)kw * a.in_sw);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], bf16_to_f32(v[e]));
+                }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(m[e]);
+        *(bf16x8*)(a.y + n * a.out_sn + (long long)d * a.out_sd + (long long)h * a.out_sh + (long long)w * a.out_sw +
+                   a.out_off0 + 8 * c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// per-frame spatial mean: halo'd NHWC bf16 -> fp32 [n][c] (+ bf16 copy)
+// block = one frame; lane layout (pixel slice, 8-channel chunk)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_kernel(const short* __restrict__ x, int h, int w, int c, int halo,
+                                                      float* __restrict__ yf, short* __restrict__ yb, int ldb) {
+    __shared__ float red[256 * 8];
+    const int c8 = c >> 3;
+    const int n = blockIdx.x;
+    const int wp = w + 2 * halo, hp = h + 2 * halo;
+    const short* img = x + (long long)n * hp * wp * c;
+    const float inv = 1.0f / (float)(h * w);
+    for (int cb = 0; cb < c8; cb += 256) {           // channel chunks handled per pass
+        const int chunks = (c8 - cb) < 256 ? (c8 - cb) : 256;
+        const int slices = 256 / chunks;             // pixel slices per pass (chunks is a power of two or >= 256)
+        const int ch = threadIdx.x % chunks, sl = threadIdx.x / chunks;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (sl < slices) {
+            for (int p = sl; p < h * w; p += slices) {
+                const int py = p / w, px = p - py * w;
+                const bf16x8 v = *(const bf16x8*)(img + ((long long)(py + halo) * wp + px + halo) * c + 8 * (cb + ch));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += bf16_to_f32(v[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
+        __syncthreads();
+        if (sl == 0) {
+            for (int s2 = 1; s2 < slices; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += red[(s2 * chunks + ch) * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = acc[e] * inv;
+                yf[(long long)n * c + 8 * (cb + ch) + e] = v;
+                if (yb) yb[(long long)n * ldb + 8 * (cb + ch) + e] = f32_to_bf16(v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void mean_t_kernel(const float* __restrict__ x, int rows, int t, int c,
+                                                     float* __restrict__ y) {
+    const long long total = (long long)rows * c;
+    const float inv = 1.0f / (float)t;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / c;
+        const int ch = (int)(i - r * c);
+        const float* p = x + r * t * c + ch;
+        float s = 0.f;
+        for (int k = 0; k < t; ++k) s += p[(long long)k * c];
+        y[i] = s * inv;
+    }
+}
+
+// one wave per output element: dot product over f with a shuffle reduction
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, int m, int f,
+                                                   const float* __restrict__ w, const float* __restrict__ b, int c,
+                                                   float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (blockIdx.x * 256LL + threadIdx.x) >> 6;
+    if (wid >= (long long)m * c) return;
+    const int row = (int)(wid / c), col = (int)(wid % c);
+    const float* xr = x + (long long)row * f;
+    const float* wr = w + (long long)col * f;
+    float s = 0.f;
+    for (int k = lane; k < f; k += 64) s += xr[k] * wr[k];
+    s = wave_sum(s);
+    if (lane == 0) y[wid] = s + (b ? b[col] : 0.f);
+}
+
+// one block per row: softmax statistics, then k rounds of arg-max over the row kept in LDS
+__global__ __launch_bounds__(256) void softmax_topk_kernel(const float* __restrict__ logits, int c, int k,
+                                                           int64_t* __restrict__ idx, float* __restrict__ prob) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* v = (float*)smem_raw;              // [c]
+    __shared__ float wred[4];
+    __shared__ int wredi[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* lr = logits + (long long)row * c;
+    float mx = -INFINITY;
+    for (int i = tid; i < c; i += 256) { v[i] = lr[i]; mx = fmaxf(mx, lr[i]); }
+    mx = wave_max(mx);
+    if (lane == 0) wred[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < c; i += 256) sum += expf(v[i] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) wred[wv] = sum;
+    __syncthreads();
+    sum = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+    __syncthreads();
+    for (int r = 0; r < k; ++r) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < c; i += 256)
+            if (v[i] > best) { best = v[i]; bi = i; }     // ascending i: first maximum wins
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { wred[wv] = best; wredi[wv] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int q = 1; q < 4; ++q)
+                if (wred[q] > best || (wred[q] == best && wredi[q] < bi)) { best = wred[q]; bi = wredi[q]; }
+            idx[(long long)row * k + r] = bi;
+            prob[(long long)row * k + r] = expf(best - mx) / sum;
+            v[bi] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
+int grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace
+
+extern "C" int asl_pack_clips(const void* clips, int in_f32, int n, int s, void* y, asl_stream_t stream) {
+    if (!clips || !y || n <= 0 || s <= 0 || (s & 1) || ((uintptr_t)y & 15)) return ASL_EINVAL;
+    const long long total = (long long)n * (s + 6) * ((s + 6) / 2);
+    hipStream_t st = (hipStream_t)stream;
+    if (in_f32) hipLaunchKernelGGL(pack_clips_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, (short*)y);
+    else hipLaunchKernelGGL(pack_clips_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, (short*)y);
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, int s, const float mean[3],
+                                 const float std_[3], void* y, float* clips_f32, asl_stream_t stream) {
+    if (!frames || !y || !mean || !std_ || n <= 0 || h0 <= 0 || w0 <= 0 || s <= 0 || ((uintptr_t)y & 7))
+        return ASL_EINVAL;
+    for (int c = 0; c < 3; ++c)
+        if (!(std_[c] > 0.f)) return ASL_EINVAL;
+    const long long total = (long long)n * (s + 6) * (s + 6);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, n, h0, w0,
+                       s, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], (short*)y,
+                       clips_f32);
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_maxpool3d_ndhwc(const asl_pool3d_params* p, const void* x, void* y, asl_stream_t stream) {
+    if (!p || !x || !y) return ASL_EINVAL;
+    if (p->n <= 0 || p->d <= 0 || p->h <= 0 || p->w <= 0 || p->c <= 0 || (p->c & 7)) return ASL_EINVAL;
+    if (p->kd <= 0 || p->kh <= 0 || p->kw <= 0 || p->sd <= 0 || p->sh <= 0 || p->sw <= 0) return ASL_EINVAL;
+    if (p->pd < 0 || p->ph < 0 || p->pw < 0 || p->pd > p->in_halo_d || p->ph > p->in_halo || p->pw > p->in_halo)
+        return ASL_EINVAL;
+    // every window must hold at least one real cell for the zero halo to stand in for -inf
+    if (p->pd >= p->kd || p->ph >= p->kh || p->pw >= p->kw) return ASL_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return ASL_EINVAL;
+    PoolArgs a;
+    a.x = (const short*)x; a.y = (short*)y;
+    a.n = p->n; a.c8 = p->c / 8;
+    a.od = (p->d + 2 * p->pd - p->kd) / p->sd + 1;
+    a.oh = (p->h + 2 * p->ph - p->kh) / p->sh + 1;
+    a.ow = (p->w + 2 * p->pw - p->kw) / p->sw + 1;
+    if (a.od <= 0 || a.oh <= 0 || a.ow <= 0) return ASL_EINVAL;
+    // the last window must not run past the halo
+    if ((a.od - 1) * p->sd - p->pd + p->kd > p->d + p->in_halo_d) return ASL_EINVAL;
+    if ((a.oh - 1) * p->sh - p->ph + p->kh > p->h + p->in_halo) return ASL_EINVAL;
+    if ((a.ow - 1) * p->sw - p->pw + p->kw > p->w + p->in_halo) return ASL_EINVAL;
+    a.kd = p->kd; a.kh = p->kh; a.kw = p->kw; a.sd = p->sd; a.sh = p->sh; a.sw = p->sw;
+    const int wp = p->w + 2 * p->in_halo, hp = p->h + 2 * p->in_halo, dp = p->d + 2 * p->in_halo_d;
+    a.in_sw = p->c; a.in_sh = wp * p->c; a.in_sd = hp * wp * p->c; a.in_sn = (long long)dp * hp * wp * p->c;
+    a.in_off0 = (p->in_halo_d - p->pd) * a.in_sd + (p->in_halo - p->ph) * a.in_sh + (p->in_halo - p->pw) * a.in_sw;
+    const int owp = a.ow + 2 * p->out_halo, ohp = a.oh + 2 * p->out_halo, odp = a.od + 2 * p->out_halo_d;
+    a.out_sw = p->c; a.out_sh = owp * p->c; a.out_sd = ohp * owp * p->c;
+    a.out_sn = (long long)odp * ohp * owp * p->c;
+    a.out_off0 = p->out_halo_d * a.out_sd + p->out_halo * a.out_sh + p->out_halo * a.out_sw;
+    const long long total = (long long)a.n * a.od * a.oh * a.ow * a.c8;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_maxpool3x3s2_nhwc(const void* x, int n, int h, int w, int c, int in_halo, void* y, int out_halo,
+                                     asl_stream_t stream) {
+    asl_pool3d_params p;
+    p.n = n; p.d = 1; p.h = h; p.w = w; p.c = c; p.in_halo_d = 0; p.in_halo = in_halo;
+    p.kd = 1; p.kh = 3; p.kw = 3; p.sd = 1; p.sh = 2; p.sw = 2; p.pd = 0; p.ph = 1; p.pw = 1;
+    p.out_halo_d = 0; p.out_halo = out_halo;
+    if (in_halo < 1 || out_halo < 0) return ASL_EINVAL;
+    return asl_maxpool3d_ndhwc(&p, x, y, stream);
+}
+
+extern "C" int asl_avgpool_nhwc(const void* x, int n, int h, int w, int c, int halo, float* y_f32, void* y_bf16,
+                                int ld_bf16, asl_stream_t stream) {
+    if (!x || !y_f32 || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 7) || halo < 0) return ASL_EINVAL;
+    const int c8 = c / 8;
+    if (c8 < 256 && (c8 & (c8 - 1))) return ASL_EINVAL;       // lane layout needs 256 % chunks == 0
+    if (c8 > 256 && (c8 % 256)) return ASL_EINVAL;
+    if (y_bf16 && ld_bf16 < c) return ASL_EINVAL;
+    if ((uintptr_t)x & 15) return ASL_EINVAL;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const short*)x, h, w, c, halo,
+                       y_f32, (short*)y_bf16, ld_bf16);
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_mean_t_f32(const float* x, int rows, int t, int c, float* y, asl_stream_t stream) {
+    if (!x || !y || rows <= 0 || t <= 0 || c <= 0) return ASL_EINVAL;
+    hipLaunchKernelGGL(mean_t_kernel, dim3(grid_for((long long)rows * c)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       t, c, y);
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_head_f32(const float* x, int m, int f, const float* w, const float* b, int c, float* y,
+                            asl_stream_t stream) {
+    if (!x || !w || !y || m <= 0 || f <= 0 || c <= 0) return ASL_EINVAL;
+    const long long waves = (long long)m * c;
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, m, f, w,
+                       b, c, y);
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_softmax_topk(const float* logits, int m, int c, int k, int64_t* idx, float* prob,
+                                asl_stream_t stream) {
+    if (!logits || !idx || !prob || m <= 0 || c <= 0 || k <= 0 || k > 16 || k > c || c > 12288) return ASL_EINVAL;
+    hipLaunchKernelGGL(softmax_topk_kernel, dim3(m), dim3(256), (size_t)c * 4, (hipStream_t)stream, logits, c, k, idx,
+                       prob);
+    return (int)hipGetLastError();
+}
