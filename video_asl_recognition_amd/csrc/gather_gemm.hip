@@ -15,7 +15,7 @@
 #include "asl_hip.h"
 #include "common.h"
 
-namespace {
+namespace asl_detail {
 
 struct GemmArgs {
     const char* x;
@@ -52,6 +52,7 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 
 template <int BM, int BN, int BK, int WGM, int WGN>
 __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub; the body uses device-only types
     constexpr int NW = WGM * WGN;
     constexpr int RB = BK * 2;        // bytes per staged row
     constexpr int CPR = RB / 16;      // 16-byte chunks per row
@@ -257,19 +258,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
             }
         }
     }
+#endif
 }
+
 
 template <int BM, int BN, int BK, int WGM, int WGN>
 int launch(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * BK * 2;
     static_assert(lds <= 65536, "tiles above 64 KiB of LDS need hipFuncSetAttribute");
-    auto kern = gather_gemm_kernel<BM, BN, BK, WGM, WGN>;
     GemmArgs b = a;
     b.tiles_m = (a.M + BM - 1) / BM;
     b.tiles_n = (a.N + BN - 1) / BN;
     const long long nblk = (long long)b.tiles_m * b.tiles_n;
     if (nblk > 0x7fffffffLL) return ASL_EINVAL;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WGM * WGN * 64), lds, stream, b);
+    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, BK, WGM, WGN>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), lds, stream, b);
     return (int)hipGetLastError();
 }
 
@@ -281,7 +283,8 @@ long long geom_extent(const asl_geom& g, int nb, int od, int oh, int ow) {
 
 bool geom_nonneg(const asl_geom& g) { return g.sn >= 0 && g.sd >= 0 && g.sh >= 0 && g.sw >= 0 && g.off0 >= 0; }
 
-}  // namespace
+}  // namespace asl_detail
+using namespace asl_detail;
 
 extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, const void* w, const float* scale,
                                     const float* bias, const void* res, void* y, asl_stream_t stream) {

@@ -6,7 +6,7 @@
 #include "asl_hip.h"
 #include "common.h"
 
-namespace {
+namespace asl_detail {
 
 constexpr int kHalo0 = 3;   // halo of the packed stem input (the 7x7 stem's padding)
 
@@ -264,7 +264,8 @@ int grid_for(long long total) {
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
 
-}  // namespace
+}  // namespace asl_detail
+using namespace asl_detail;
 
 extern "C" int asl_pack_clips(const void* clips, int in_f32, int n, int s, void* y, asl_stream_t stream) {
     if (!clips || !y || n <= 0 || s <= 0 || (s & 1) || ((uintptr_t)y & 15)) return ASL_EINVAL;
