@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the clip -> logits hot path: ResNet-18 per-frame backbone + mean over T +
+Linear(512,100), T=64, 224x224, bf16, synthetic clips resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A step = one forward() over one batch of `--clips` clips per GPU (pack -> stem -> maxpool ->
+20 convs -> avg-pool -> mean over T -> head) plus, for N>1, the RCCL all-gather of the logits.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the gather-GEMM conv
+kernel, all of its launches in a step) against the dense bf16 MFMA peak; `cpu_baseline` is the
+PyTorch-CPU-eager oracle timed on this host's cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2516.6            # 256 CU x 4096 bf16 FLOP/clk/CU x 2.4 GHz, dense
+R18_CONV_MAC_PER_FRAME = 1_813_561_344   # conv MACs only, unpadded, 224x224
+
+
+def conv_flops_per_frame(model):
+    """Algorithmic conv FLOPs per frame from the loaded weights (cross-check of the constant)."""
+    from video_asl_recognition_amd.spec import resnet_blocks
+    S = model.spec.size
+    mac = (S // 2) ** 2 * 64 * 147
+    hw = S // 4
+    for prefix, cin, planes, stride, ds in resnet_blocks("resnet18"):
+        hw //= stride
+        mac += hw * hw * planes * cin * 9 + hw * hw * planes * planes * 9
+        if ds:
+            mac += hw * hw * planes * cin
+    return 2 * mac
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips", type=int, default=8, help="clips per GPU per step")
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("ASL_CHUNK", "256")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from video_asl_recognition_amd import AslClipModel, gather_logits, init_state_dict
+    from video_asl_recognition_amd.spec import SPECS
+
+    spec = SPECS["resnet18_mean"]
+    B, T, S = args.clips, args.frames, spec.size
+    model = AslClipModel(spec, device=str(dev), frames_per_chunk=args.chunk)
+    use_oracle = rank == 0 and world == 1 and not args.no_cpu_baseline
+    oracle = None
+    if use_oracle:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import asl_oracle as O
+        oracle = O.build("resnet18_mean", seed=0)
+        model.load_state_dict(oracle.state_dict())
+    else:
+        model.load_state_dict(init_state_dict(spec, seed=0))
+
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    clips = torch.randn(B, T, 3, S, S, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+
+    def step():
+        return gather_logits(model(clips))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert out.shape == (B * world, spec.num_classes)
+    clips_per_s = world * B * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: every gather-GEMM (conv) launch of one step, timed
+        # with events on the launch stream in an instrumented pass over the same inputs
+        conv_ms, launches = time_conv_launches(model, clips, passes=3)
+        flops_step = conv_flops_per_frame(model) * B * T
+        assert conv_flops_per_frame(model) == 2 * R18_CONV_MAC_PER_FRAME
+        achieved = flops_step / (conv_ms * 1e-3) / 1e12
+        result = {
+            "metric": "clips/sec end-to-end (T=64, 224x224, bf16)",
+            "value": round(clips_per_s, 2),
+            "unit": "clips/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "resnet18_mean: ResNet-18 per frame + mean over T + Linear(512,100), "
+                                   f"T={T}, {S}x{S}, {B} clips/GPU/step, random-init weights, clips resident in HBM",
+                       "clips_per_gpu": B, "frames_per_clip": T, "frames_per_chunk": args.chunk,
+                       "parallelism": f"batch-sharded x{world}, all-gather of logits"},
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "gather_gemm_kernel (all conv launches of one step)",
+                "achieved": round(achieved, 2),
+                "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "launches_per_step": launches,
+                "avg_launch_us": round(conv_ms * 1e3 / launches, 2),
+                "algorithmic_gflop_per_step": round(flops_step / 1e9, 1),
+                "end_to_end_frac": round(clips_per_s / world * T * conv_flops_per_frame(model) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            },
+        }
+        if use_oracle:
+            result["cpu_baseline"], result["parity"] = cpu_baseline(oracle, model, T, S)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def time_conv_launches(model, clips, passes=3):
+    """Sum of the gather-GEMM launch durations of one step (ms) and their count, from events
+    recorded around each conv launch on the launch stream."""
+    import ctypes as C
+    plan = model._get_plan(clips.shape[0] * clips.shape[1])
+    n_total = clips.shape[0] * clips.shape[1]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    conv_ops = [op for op in plan["ops"] if op.__name__ == "run"]
+    best = None
+    for _ in range(passes):
+        total_ms, launches = 0.0, 0
+        for c0 in range(0, n_total, plan["nmax"]):
+            n = min(plan["nmax"], n_total - c0)
+            evs = []
+            for op in plan["ops"]:
+                if op in conv_ops:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    op(n, stream)
+                    e1.record()
+                    evs.append((e0, e1))
+                else:
+                    op(n, stream)
+            torch.cuda.synchronize()
+            total_ms += sum(a.elapsed_time(b) for a, b in evs)
+            launches += len(evs)
+        best = total_ms if best is None else min(best, total_ms)
+    return best, launches
+
+
+def cpu_baseline(oracle, model, T, S):
+    """The PyTorch-CPU-eager oracle on this host: 1 clip (T frames), 1 warm-up + 3 timed forwards;
+    the same clip through the GPU path gives the parity figures."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import asl_oracle as O
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    clip = O.make_clips(1, T, S, seed=0)
+    with torch.no_grad():
+        ref = oracle(clip)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            ref = oracle(clip)
+        dt = (time.perf_counter() - t0) / reps
+    y = model(clip.cuda()).cpu()
+    rel = float((y - ref).norm() / ref.norm())
+    base = {"value": round(1.0 / dt, 3), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"1 clip x {T} frames {S}x{S} fp32, torch.nn CPU eager oracle, 1 warm-up + {reps} timed forwards"}
+    parity = {"rel_l2_vs_cpu_oracle": rel, "argmax_identical": bool(torch.equal(y.argmax(1), ref.argmax(1))),
+              "tolerance": 1e-3}
+    return base, parity
+
+
+if __name__ == "__main__":
+    main()

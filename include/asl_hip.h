@@ -100,18 +100,24 @@ int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, const void* 
                          const float* scale, const float* bias, const void* res, void* y,
                          asl_stream_t stream);
 
-/* The ResNet stem: nn.Conv2d(3, cout, 7, stride 2, pad 3, bias=False) + BatchNorm2d(eval) +
- * ReLU.  x is the packed clip tensor written by asl_pack_clips / asl_preprocess_u8:
- * [n][h+6][w+6][4] bf16 (channel 3 zero, halo 3).  w packed [w_rows][7*32]: for filter row
- * r, 8 pixels x 4 channels with pixel 7 and channel 3 zero.  y: [n][h/2+2*out_halo][..][cout]. */
+/* First-layer convolution on packed RGB: nn.Conv2d(3, cout, (kh,kw), stride, pad) [+ BatchNorm2d
+ * (eval)] [+ ReLU], e.g. the ResNet stem (7x7, stride 2, pad 3).  x is the packed clip tensor
+ * written by asl_pack_clips / asl_preprocess_u8: [n][h+2*in_halo][w+2*in_halo][4] bf16 with
+ * channel 3 zero.  One K "tap" per filter row: 8 pixels x 4 channels = 32 contiguous elements,
+ * so kw <= 8 and w packed [w_rows][kh*32] with w[co][r*32 + q*4 + c] (q >= kw, c == 3 zero).
+ * Requires in_halo >= pad and in_halo >= (ow-1)*stride - pad + 8 - w so the 8-pixel window of
+ * the last column stays inside the row (7x7/2/3 on even w: in_halo = 3).
+ * y: [n][oh+2*out_halo][ow+2*out_halo][cout]. */
 typedef struct asl_stem_params {
-    int32_t n, h, w;
-    int32_t cout, out_halo;
+    int32_t n, h, w, in_halo;
+    int32_t cout, kh, kw, stride, pad;
+    int32_t out_halo;
+    int32_t relu;
     int32_t w_rows;
 } asl_stem_params;
 
-int asl_stem7x7_bf16(const asl_stem_params* p, const void* x, const void* w,
-                     const float* scale, const float* bias, void* y, asl_stream_t stream);
+int asl_stem_conv_bf16(const asl_stem_params* p, const void* x, const void* w,
+                       const float* scale, const float* bias, void* y, asl_stream_t stream);
 
 /* nn.Conv3d(cin, cout, (kd,kh,kw), stride, pad=k//2, bias=False) + BatchNorm3d(eval) + ReLU
  * on halo'd NDHWC bf16: x [n][d+2*in_halo_d][h+2*in_halo][w+2*in_halo][cin]. */
@@ -144,14 +150,15 @@ int asl_linear_bf16(const asl_linear_params* p, const void* x, const void* w,
  * ---------------------------------------------------------------------------------- */
 
 /* clips [n][3][s][s] (fp32 if in_f32 else bf16), i.e. the [B,T,3,S,S] forward() argument
- * flattened over B*T  ->  packed stem input [n][s+6][s+6][4] bf16, halo and channel 3
- * zeroed by this kernel. */
-int asl_pack_clips(const void* clips, int in_f32, int n, int s, void* y, asl_stream_t stream);
+ * flattened over B*T  ->  packed first-layer input [n][s+2*halo][s+2*halo][4] bf16; halo and
+ * channel 3 are zeroed by this kernel.  s must be even. */
+int asl_pack_clips(const void* clips, int in_f32, int n, int s, int halo, void* y,
+                   asl_stream_t stream);
 
 /* F.interpolate(bilinear, align_corners=False, antialias=False) + /255 + (x-mean)/std:
- * frames uint8 [n][h0][w0][3]  ->  packed stem input [n][s+6][s+6][4] bf16 (as above).
- * If clips_f32 != NULL the normalised fp32 [n][3][s][s] tensor is written as well. */
-int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, int s,
+ * frames uint8 [n][h0][w0][3]  ->  packed first-layer input [n][s+2*halo][s+2*halo][4] bf16
+ * (as above).  If clips_f32 != NULL the normalised fp32 [n][3][s][s] tensor is written as well. */
+int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, int s, int halo,
                       const float mean[3], const float std_[3], void* y, float* clips_f32,
                       asl_stream_t stream);
 

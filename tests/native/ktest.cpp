@@ -156,7 +156,7 @@ static void check_stem(int n, int s, int cout, int out_halo) {
     dclips.up(clips);
     DBuf<uint16_t> dx((size_t)n * sp * sp * 4);
     HIP_CHECK(hipMemset(dx.p, 0x7f, dx.n * 2));
-    int rc = asl_pack_clips(dclips.p, 1, n, s, dx.p, nullptr);
+    int rc = asl_pack_clips(dclips.p, 1, n, s, 3, dx.p, nullptr);
     if (rc) { printf("pack_clips rc=%d FAIL\n", rc); ++g_fail; return; }
     HIP_CHECK(hipDeviceSynchronize());
     auto xp = dx.down();
@@ -188,8 +188,8 @@ static void check_stem(int n, int s, int cout, int out_halo) {
     DBuf<float> dsc(cout), dbi(cout);
     dw.up(wp); dsc.up(sc); dbi.up(bi);
     HIP_CHECK(hipMemset(dy.p, 0x7f, dy.n * 2));
-    asl_stem_params p = {n, s, s, cout, out_halo, wrows};
-    rc = asl_stem7x7_bf16(&p, dx.p, dw.p, dsc.p, dbi.p, dy.p, nullptr);
+    asl_stem_params p = {n, s, s, 3, cout, 7, 7, 2, 3, out_halo, 1, wrows};
+    rc = asl_stem_conv_bf16(&p, dx.p, dw.p, dsc.p, dbi.p, dy.p, nullptr);
     if (rc) { printf("stem rc=%d (%s) FAIL\n", rc, asl_strerror(rc)); ++g_fail; return; }
     HIP_CHECK(hipDeviceSynchronize());
     auto y = dy.down();
@@ -395,11 +395,11 @@ static void bench(int frames) {
         for (auto& v : hx) v = f2bf(urand(-1, 1));
         for (auto& v : hw) v = f2bf(urand(-0.1f, 0.1f));
         dx.up(hx); dw.up(hw); dy.zero();
-        asl_stem_params p = {frames, s, s, 64, 1, 128};
-        for (int it = 0; it < 2; ++it) asl_stem7x7_bf16(&p, dx.p, dw.p, nullptr, nullptr, dy.p, nullptr);
+        asl_stem_params p = {frames, s, s, 3, 64, 7, 7, 2, 3, 1, 1, 128};
+        for (int it = 0; it < 2; ++it) asl_stem_conv_bf16(&p, dx.p, dw.p, nullptr, nullptr, dy.p, nullptr);
         HIP_CHECK(hipEventRecord(e0));
         const int iters = 5;
-        for (int it = 0; it < iters; ++it) asl_stem7x7_bf16(&p, dx.p, dw.p, nullptr, nullptr, dy.p, nullptr);
+        for (int it = 0; it < iters; ++it) asl_stem_conv_bf16(&p, dx.p, dw.p, nullptr, nullptr, dy.p, nullptr);
         HIP_CHECK(hipEventRecord(e1));
         HIP_CHECK(hipEventSynchronize(e1));
         float ms;

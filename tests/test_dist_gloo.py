@@ -1,0 +1,42 @@
+"""CPU, world_size 2 (gloo): the multi-GPU layer's semantics -- contiguous batch shards and an
+all-gather of per-rank logits that equals the single-process result, rank order preserved."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from video_asl_recognition_amd.dist import gather_logits, shard_batch
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, Cn = 6, 10
+        full = torch.arange(B * Cn, dtype=torch.float32).view(B, Cn) * 0.5   # "logits" of the whole batch
+        lo, hi = shard_batch(B, rank, world)
+        got = gather_logits(full[lo:hi].clone())
+        torch.save({"ok": bool(torch.equal(got, full)), "shape": tuple(got.shape)}, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_logits_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(tmp_path, f"r{r}.pt"))
+        assert res["ok"] and res["shape"] == (6, 10)
+
+
+def test_gather_is_identity_without_process_group():
+    x = torch.randn(3, 4)
+    assert gather_logits(x) is x

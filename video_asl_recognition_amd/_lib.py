@@ -1,0 +1,98 @@
+"""ctypes binding of libaslhip.so (the C ABI declared in include/asl_hip.h).
+
+The library is built in-tree by ``video_asl_recognition_amd/csrc/Makefile`` (``__graft_entry__.build()``
+runs it).  There is no fallback: if the shared object is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libaslhip.so")
+
+ASL_OK, ASL_EINVAL, ASL_ENOTSUP = 0, -1, -2
+
+
+class Geom(C.Structure):
+    _fields_ = [("sn", C.c_int64), ("sd", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32), ("off0", C.c_int32)]
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("nb", C.c_int32), ("od", C.c_int32), ("oh", C.c_int32), ("ow", C.c_int32),
+                ("cout", C.c_int32), ("kd", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("ck", C.c_int32), ("tap_sd", C.c_int32), ("tap_sh", C.c_int32), ("tap_sw", C.c_int32),
+                ("in_", Geom), ("out", Geom), ("res", Geom),
+                ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32),
+                ("x_elems", C.c_int64), ("y_elems", C.c_int64), ("res_elems", C.c_int64)]
+
+
+class Conv2dParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "h", "w", "cin", "in_halo", "cout", "kh", "kw", "stride", "pad",
+        "out_halo", "out_ctot", "out_coff", "res_halo", "res_ctot", "res_coff", "relu", "w_rows")]
+
+
+class StemParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "h", "w", "in_halo", "cout", "kh", "kw", "stride", "pad", "out_halo", "relu", "w_rows")]
+
+
+class Conv3dParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "d", "h", "w", "cin", "in_halo_d", "in_halo", "cout", "kd", "kh", "kw", "stride_d", "stride",
+        "pad_d", "pad", "out_halo_d", "out_halo", "out_ctot", "out_coff", "relu", "w_rows")]
+
+
+class LinearParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("m", "n", "k", "ldx", "ldy", "ldres", "relu", "out_f32", "w_rows")]
+
+
+class Pool3dParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "d", "h", "w", "c", "in_halo_d", "in_halo", "kd", "kh", "kw", "sd", "sh", "sw",
+        "pd", "ph", "pw", "out_halo_d", "out_halo")]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+        "(or __graft_entry__.build()); this package has no non-HIP fallback")
+
+lib = C.CDLL(LIB_PATH)
+
+_P, _I, _F3 = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+
+_PROTOS = {
+    "asl_version": ([], C.c_int),
+    "asl_strerror": ([C.c_int], C.c_char_p),
+    "asl_gather_gemm_bf16": ([C.POINTER(GemmParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_conv2d_nhwc_bf16": ([C.POINTER(Conv2dParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_stem_conv_bf16": ([C.POINTER(StemParams), _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_conv3d_ndhwc_bf16": ([C.POINTER(Conv3dParams), _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_linear_bf16": ([C.POINTER(LinearParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_pack_clips": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
+    "asl_preprocess_u8": ([_P, _I, _I, _I, _I, _I, _F3, _F3, _P, _P, _P], C.c_int),
+    "asl_maxpool3x3s2_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "asl_maxpool3d_ndhwc": ([C.POINTER(Pool3dParams), _P, _P, _P], C.c_int),
+    "asl_avgpool_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _P, _I, _P], C.c_int),
+    "asl_mean_t_f32": ([_P, _I, _I, _I, _P, _P], C.c_int),
+    "asl_head_f32": ([_P, _I, _I, _P, _P, _I, _P, _P], C.c_int),
+    "asl_softmax_topk": ([_P, _I, _I, _I, _P, _P, _P], C.c_int),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+for _name, (_args, _res) in _PROTOS.items():
+    _fn = getattr(lib, _name)      # AttributeError here = the .so is stale; rebuild it
+    _fn.argtypes = _args
+    _fn.restype = _res
+
+
+def strerror(rc: int) -> str:
+    return lib.asl_strerror(rc).decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what or 'asl call'} failed: rc={rc} ({strerror(rc)})")

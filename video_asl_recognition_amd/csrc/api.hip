@@ -51,26 +51,30 @@ extern "C" int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, c
     return asl_gather_gemm_bf16(&g, x, w, scale, bias, res, y, stream);
 }
 
-extern "C" int asl_stem7x7_bf16(const asl_stem_params* p, const void* x, const void* w, const float* scale,
-                                const float* bias, void* y, asl_stream_t stream) {
+extern "C" int asl_stem_conv_bf16(const asl_stem_params* p, const void* x, const void* w, const float* scale,
+                                  const float* bias, void* y, asl_stream_t stream) {
     if (!p) return ASL_EINVAL;
-    if (p->n <= 0 || p->h <= 0 || p->w <= 0 || (p->h & 1) || (p->w & 1) || p->cout <= 0 || p->out_halo < 0)
+    if (p->n <= 0 || p->h <= 0 || p->w <= 0 || p->cout <= 0 || p->out_halo < 0) return ASL_EINVAL;
+    if (p->kh <= 0 || p->kw <= 0 || p->kw > 8 || p->stride <= 0 || p->pad < 0 || p->in_halo < p->pad)
         return ASL_EINVAL;
-    const int oh = p->h / 2, ow = p->w / 2;           // (h + 6 - 7) / 2 + 1 for even h
-    const int wp = p->w + 6, hp = p->h + 6;
+    const int oh = (p->h + 2 * p->pad - p->kh) / p->stride + 1;
+    const int ow = (p->w + 2 * p->pad - p->kw) / p->stride + 1;
+    if (oh <= 0 || ow <= 0) return ASL_EINVAL;
+    // the 8-pixel window of the last output column must end inside the (halo'd) row
+    if ((ow - 1) * p->stride - p->pad + 8 > p->w + p->in_halo) return ASL_EINVAL;
+    const int wp = p->w + 2 * p->in_halo, hp = p->h + 2 * p->in_halo;
     asl_gemm_params g = {};
     g.nb = p->n; g.od = 1; g.oh = oh; g.ow = ow; g.cout = p->cout;
-    // one "tap" per filter row: 8 pixels x 4 channels = 32 contiguous elements (pixel 7, channel 3
-    // carry zero weights)
-    g.kd = 1; g.kh = 7; g.kw = 1; g.ck = 32;
+    // one "tap" per filter row: 8 pixels x 4 channels = 32 contiguous elements (pixels >= kw and
+    // channel 3 carry zero weights)
+    g.kd = 1; g.kh = p->kh; g.kw = 1; g.ck = 32;
     g.tap_sd = 0; g.tap_sh = wp * 4; g.tap_sw = 0;
-    g.in.sn = (int64_t)hp * wp * 4; g.in.sd = 0; g.in.sh = 2 * wp * 4; g.in.sw = 2 * 4; g.in.off0 = 0;
+    g.in.sn = (int64_t)hp * wp * 4; g.in.sd = 0; g.in.sh = p->stride * wp * 4; g.in.sw = p->stride * 4;
+    g.in.off0 = ((p->in_halo - p->pad) * wp + (p->in_halo - p->pad)) * 4;
     const int owp = ow + 2 * p->out_halo, ohp = oh + 2 * p->out_halo;
     g.out.sn = (int64_t)ohp * owp * p->cout; g.out.sd = 0; g.out.sh = owp * p->cout; g.out.sw = p->cout;
     g.out.off0 = (p->out_halo * owp + p->out_halo) * p->cout;
-    g.relu = 1; g.out_f32 = 0; g.w_rows = p->w_rows;
-    // the last pixel's 8-pixel window ends exactly at the right halo edge; the packed tensor
-    // is followed by nothing, so the window of the very last row needs no slack either
+    g.relu = p->relu; g.out_f32 = 0; g.w_rows = p->w_rows;
     g.x_elems = (int64_t)p->n * g.in.sn;
     g.y_elems = (int64_t)p->n * g.out.sn;
     return asl_gather_gemm_bf16(&g, x, w, scale, bias, nullptr, y, stream);

@@ -8,14 +8,12 @@
 
 namespace asl_detail {
 
-constexpr int kHalo0 = 3;   // halo of the packed stem input (the 7x7 stem's padding)
-
 // ---------------------------------------------------------------------------------------
-// clips [n][3][s][s] -> packed [n][s+6][s+6][4] bf16; one lane per 2 output pixels (16 B)
+// clips [n][3][s][s] -> packed [n][s+2*halo][s+2*halo][4] bf16; one lane per 2 output pixels (16 B)
 // ---------------------------------------------------------------------------------------
 template <bool F32>
 __global__ __launch_bounds__(256) void pack_clips_kernel(const void* __restrict__ clips, int n, int s,
-                                                         short* __restrict__ y) {
+                                                         int kHalo0, short* __restrict__ y) {
     const int sp = s + 2 * kHalo0;          // even: s is even
     const int pairs_per_row = sp / 2;
     const long long total = (long long)n * sp * pairs_per_row;
@@ -51,8 +49,8 @@ __global__ __launch_bounds__(256) void pack_clips_kernel(const void* __restrict_
 // guard_index_and_lambda for align_corners=False (scale = in/out in fp32).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ frames, int n, int h0, int w0,
-                                                         int s, float m0, float m1, float m2, float i0, float i1,
-                                                         float i2, short* __restrict__ y,
+                                                         int s, int kHalo0, float m0, float m1, float m2, float i0,
+                                                         float i1, float i2, short* __restrict__ y,
                                                          float* __restrict__ clips_f32) {
     const int sp = s + 2 * kHalo0;
     const long long total = (long long)n * sp * sp;
@@ -267,24 +265,24 @@ int grid_for(long long total) {
 }  // namespace asl_detail
 using namespace asl_detail;
 
-extern "C" int asl_pack_clips(const void* clips, int in_f32, int n, int s, void* y, asl_stream_t stream) {
-    if (!clips || !y || n <= 0 || s <= 0 || (s & 1) || ((uintptr_t)y & 15)) return ASL_EINVAL;
-    const long long total = (long long)n * (s + 6) * ((s + 6) / 2);
+extern "C" int asl_pack_clips(const void* clips, int in_f32, int n, int s, int halo, void* y, asl_stream_t stream) {
+    if (!clips || !y || n <= 0 || s <= 0 || (s & 1) || halo < 0 || ((uintptr_t)y & 15)) return ASL_EINVAL;
+    const long long total = (long long)n * (s + 2 * halo) * ((s + 2 * halo) / 2);
     hipStream_t st = (hipStream_t)stream;
-    if (in_f32) hipLaunchKernelGGL(pack_clips_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, (short*)y);
-    else hipLaunchKernelGGL(pack_clips_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, (short*)y);
+    if (in_f32) hipLaunchKernelGGL(pack_clips_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, halo, (short*)y);
+    else hipLaunchKernelGGL(pack_clips_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, halo, (short*)y);
     return (int)hipGetLastError();
 }
 
-extern "C" int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, int s, const float mean[3],
+extern "C" int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, int s, int halo, const float mean[3],
                                  const float std_[3], void* y, float* clips_f32, asl_stream_t stream) {
-    if (!frames || !y || !mean || !std_ || n <= 0 || h0 <= 0 || w0 <= 0 || s <= 0 || ((uintptr_t)y & 7))
+    if (!frames || !y || !mean || !std_ || n <= 0 || h0 <= 0 || w0 <= 0 || s <= 0 || halo < 0 || ((uintptr_t)y & 7))
         return ASL_EINVAL;
     for (int c = 0; c < 3; ++c)
         if (!(std_[c] > 0.f)) return ASL_EINVAL;
-    const long long total = (long long)n * (s + 6) * (s + 6);
+    const long long total = (long long)n * (s + 2 * halo) * (s + 2 * halo);
     hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, n, h0, w0,
-                       s, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], (short*)y,
+                       s, halo, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], (short*)y,
                        clips_f32);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,358 @@
+"""AslClipModel: the clip -> logits path on one MI355X, driven from Python.
+
+Surface (the "forward()/classify-clip API" the path must keep):
+    model = AslClipModel(spec)                 # spec: ModelSpec or its name
+    model.load_state_dict(sd)                  # oracle / torchvision-style parameter names
+    logits = model(clips, keypoints=None)      # clips [B,T,3,S,S] float -> [B,C] float32
+    idx, prob = model.classify_clip(frames_u8, keypoints=None, topk=5)
+
+PyTorch supplies device memory and the stream; every op on the path is a launch into
+libaslhip.so through ``_lib``.  Frames run through the backbone in chunks of
+``frames_per_chunk`` so activation buffers (channels-last bf16 with a zero halo, allocated
+once and reused) stay a fixed size whatever B*T is.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from .packing import PackedConv, bn_scale_bias, pack_conv, pack_linear, pack_stem
+from .spec import RESNET_LAYERS, SPECS, ModelSpec, param_shapes, resnet_blocks
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Act:
+    """Channels-last bf16 activation buffer with a zero halo: [n][h+2*halo][w+2*halo][c]."""
+
+    def __init__(self, n, h, w, c, halo, device):
+        self.n, self.h, self.w, self.c, self.halo = n, h, w, c, halo
+        self.t = torch.zeros(n, h + 2 * halo, w + 2 * halo, c, dtype=torch.bfloat16, device=device)
+
+    @property
+    def key(self):
+        return (self.h, self.w, self.c, self.halo)
+
+    def interior(self, n=None):
+        hl = self.halo
+        t = self.t[: (n or self.n)]
+        return t[:, hl:hl + self.h, hl:hl + self.w] if hl else t
+
+
+class _BufPool:
+    def __init__(self, n, device):
+        self.n, self.device = n, device
+        self.free: Dict[tuple, List[Act]] = {}
+        self.all: List[Act] = []
+
+    def get(self, h, w, c, halo=1) -> Act:
+        lst = self.free.get((h, w, c, halo))
+        if lst:
+            return lst.pop()
+        a = Act(self.n, h, w, c, halo, self.device)
+        self.all.append(a)
+        return a
+
+    def put(self, a: Act):
+        self.free.setdefault(a.key, []).append(a)
+
+    def nbytes(self):
+        return sum(a.t.numel() * 2 for a in self.all)
+
+
+class AslClipModel:
+    def __init__(self, spec, device: str = "cuda", frames_per_chunk: int = 256, seed: Optional[int] = None):
+        self.spec: ModelSpec = SPECS[spec] if isinstance(spec, str) else spec
+        if not torch.cuda.is_available():
+            raise RuntimeError("AslClipModel needs an MI355X (no GPU visible); there is no CPU path")
+        self.device = torch.device(device)
+        self.frames_per_chunk = int(frames_per_chunk)
+        self._plan = None
+        self._w: Dict[str, PackedConv] = {}
+        self._fc_w = self._fc_b = None
+        self._temporal = None
+        if seed is not None:
+            self.load_state_dict(init_state_dict(self.spec, seed))
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        shapes = param_shapes(self.spec)
+        sd = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+        if strict:
+            missing = sorted(set(shapes) - set(sd))
+            unexpected = sorted(set(sd) - set(shapes))
+            if missing or unexpected:
+                raise KeyError(f"state_dict mismatch: missing {missing[:4]}, unexpected {unexpected[:4]}")
+        for k, shp in shapes.items():
+            if k in sd and tuple(sd[k].shape) != shp:
+                raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {shp}")
+        dev, spec, w = self.device, self.spec, {}
+        if spec.backbone == "tiny":
+            w["stem"] = pack_stem(sd["backbone.conv1.weight"], dev,
+                                  bias=sd["backbone.conv1.bias"].float().contiguous().to(dev))
+            w["conv2"] = pack_conv(sd["backbone.conv2.weight"], dev,
+                                   bias=sd["backbone.conv2.bias"].float().contiguous().to(dev))
+        elif spec.backbone in RESNET_LAYERS:
+            s, b = bn_scale_bias(sd, "backbone.bn1", 1e-5, dev)
+            w["stem"] = pack_stem(sd["backbone.conv1.weight"], dev, s, b)
+            nconv = 2 if RESNET_LAYERS[spec.backbone][0] == "basic" else 3
+            for prefix, cin, planes, stride, ds in resnet_blocks(spec.backbone):
+                for i in range(1, nconv + 1):
+                    s, b = bn_scale_bias(sd, f"{prefix}.bn{i}", 1e-5, dev)
+                    w[f"{prefix}.conv{i}"] = pack_conv(sd[f"{prefix}.conv{i}.weight"], dev, scale=s, bias=b)
+                if ds:
+                    s, b = bn_scale_bias(sd, f"{prefix}.downsample.1", 1e-5, dev)
+                    w[f"{prefix}.ds"] = pack_conv(sd[f"{prefix}.downsample.0.weight"], dev, scale=s, bias=b)
+        else:
+            raise NotImplementedError(f"backbone {spec.backbone}")
+        self._w = w
+        if spec.temporal == "mean":
+            self._fc_w = sd["fc.weight"].float().contiguous().to(dev)
+            self._fc_b = sd["fc.bias"].float().contiguous().to(dev)
+        else:
+            from .temporal import build_temporal
+            self._temporal = build_temporal(spec, sd, dev)
+        self._plan = None
+        return self
+
+    # ------------------------------------------------------------------ plan
+    def _build_plan(self, nmax: int):
+        spec, dev = self.spec, self.device
+        pool = _BufPool(nmax, dev)
+        ops = []            # callables (n, stream)
+        S = spec.size
+
+        def conv_op(pc: PackedConv, x: Act, y: Act, stride, pad, relu, res: Optional[Act] = None):
+            kd, kh, kw = pc.k
+            p = L.Conv2dParams(n=0, h=x.h, w=x.w, cin=x.c, in_halo=x.halo, cout=pc.cout, kh=kh, kw=kw,
+                               stride=stride, pad=pad, out_halo=y.halo, out_ctot=y.c, out_coff=0,
+                               res_halo=res.halo if res else 0, res_ctot=res.c if res else 0, res_coff=0,
+                               relu=int(relu), w_rows=pc.w_rows)
+            args = (_ptr(x.t), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(res.t if res else None), _ptr(y.t))
+            keep = (x, y, res, pc)
+
+            def run(n, stream, p=p, args=args, keep=keep):
+                p.n = n
+                L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(p), *args, stream), "conv2d")
+            ops.append(run)
+
+        def stem_op(pc: PackedConv, x0: torch.Tensor, in_halo, y: Act, stride, pad, relu):
+            kd, kh, kw = pc.k
+            p = L.StemParams(n=0, h=S, w=S, in_halo=in_halo, cout=pc.cout, kh=kh, kw=kw, stride=stride, pad=pad,
+                             out_halo=y.halo, relu=int(relu), w_rows=pc.w_rows)
+            args = (_ptr(x0), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(y.t))
+
+            def run(n, stream, p=p, args=args, keep=(x0, y, pc)):
+                p.n = n
+                L.check(L.lib.asl_stem_conv_bf16(C.byref(p), *args, stream), "stem")
+            ops.append(run)
+
+        if spec.backbone == "tiny":
+            in_halo = 5         # (ow-1)*2 - 1 + 8 - S for the 3x3/2/1 first layer
+            x0 = torch.zeros(nmax, S + 2 * in_halo, S + 2 * in_halo, 4, dtype=torch.bfloat16, device=dev)
+            a = pool.get(S // 2, S // 2, 32)
+            stem_op(self._w["stem"], x0, in_halo, a, 2, 1, True)
+            x = pool.get(S // 4, S // 4, 64)
+            conv_op(self._w["conv2"], a, x, 2, 1, True)
+        else:
+            in_halo = 3
+            x0 = torch.zeros(nmax, S + 6, S + 6, 4, dtype=torch.bfloat16, device=dev)
+            a = pool.get(S // 2, S // 2, 64)
+            stem_op(self._w["stem"], x0, in_halo, a, 2, 3, True)
+            x = pool.get(S // 4, S // 4, 64)
+
+            def maxpool(n, stream, a=a, x=x):
+                L.check(L.lib.asl_maxpool3x3s2_nhwc(_ptr(a.t), n, a.h, a.w, a.c, a.halo, _ptr(x.t), x.halo, stream),
+                        "maxpool")
+            ops.append(maxpool)
+            pool.put(a)
+            basic = RESNET_LAYERS[spec.backbone][0] == "basic"
+            for prefix, cin, planes, stride, ds in resnet_blocks(spec.backbone):
+                oh, ow = x.h // stride, x.w // stride
+                w = self._w
+                if basic:
+                    t = pool.get(oh, ow, planes)
+                    conv_op(w[prefix + ".conv1"], x, t, stride, 1, True)
+                    idt = x
+                    if ds:
+                        idt = pool.get(oh, ow, planes)
+                        conv_op(w[prefix + ".ds"], x, idt, stride, 0, False)
+                    y = pool.get(oh, ow, planes)
+                    conv_op(w[prefix + ".conv2"], t, y, 1, 1, True, res=idt)
+                    pool.put(t)
+                else:
+                    t1 = pool.get(x.h, x.w, planes)
+                    conv_op(w[prefix + ".conv1"], x, t1, 1, 0, True)
+                    t2 = pool.get(oh, ow, planes)
+                    conv_op(w[prefix + ".conv2"], t1, t2, stride, 1, True)
+                    idt = x
+                    if ds:
+                        idt = pool.get(oh, ow, planes * 4)
+                        conv_op(w[prefix + ".ds"], x, idt, stride, 0, False)
+                    y = pool.get(oh, ow, planes * 4)
+                    conv_op(w[prefix + ".conv3"], t2, y, 1, 0, True, res=idt)
+                    pool.put(t1)
+                    pool.put(t2)
+                if ds:
+                    pool.put(idt)
+                pool.put(x)
+                x = y
+        plan = {"x0": x0, "in_halo": in_halo, "ops": ops, "last": x, "pool": pool, "nmax": nmax}
+        return plan
+
+    def _get_plan(self, n: int):
+        nmax = min(n, self.frames_per_chunk)
+        if self._plan is None or self._plan["nmax"] < nmax:
+            self._plan = self._build_plan(nmax)
+        return self._plan
+
+    # ------------------------------------------------------------------ backbone
+    def _run_backbone(self, n_total: int, fill_x0, want_bf16: bool):
+        """fill_x0(c0, n, x0, in_halo, stream) writes frames [c0, c0+n) into the packed stem input."""
+        plan = self._get_plan(n_total)
+        F = self.spec.feat_dim
+        feats = torch.empty(n_total, F, dtype=torch.float32, device=self.device)
+        feats_b = torch.empty(n_total, F, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        last: Act = plan["last"]
+        step = plan["nmax"]
+        for c0 in range(0, n_total, step):
+            n = min(step, n_total - c0)
+            fill_x0(c0, n, plan["x0"], plan["in_halo"], stream)
+            for op in plan["ops"]:
+                op(n, stream)
+            fb = None if feats_b is None else C.c_void_p(feats_b.data_ptr() + c0 * F * 2)
+            L.check(L.lib.asl_avgpool_nhwc(_ptr(last.t), n, last.h, last.w, last.c, last.halo,
+                                           C.c_void_p(feats.data_ptr() + c0 * F * 4), fb, F, stream), "avgpool")
+        return feats, feats_b
+
+    def frame_features(self, clips: torch.Tensor, want_bf16: bool = False):
+        """clips [B,T,3,S,S] -> per-frame features fp32 [B*T, F] (and their bf16 copy)."""
+        clips = self._check_clips(clips)
+        B, T, _, S, _ = clips.shape
+        esz = clips.element_size()
+        in_f32 = int(clips.dtype == torch.float32)
+        base = clips.data_ptr()
+
+        def fill(c0, n, x0, in_halo, stream):
+            L.check(L.lib.asl_pack_clips(C.c_void_p(base + c0 * 3 * S * S * esz), in_f32, n, S, in_halo,
+                                         _ptr(x0), stream), "pack_clips")
+        return self._run_backbone(B * T, fill, want_bf16)
+
+    def _check_clips(self, clips):
+        if clips.dim() != 5 or clips.shape[2] != 3 or clips.shape[3] != clips.shape[4]:
+            raise ValueError(f"clips must be [B,T,3,S,S], got {tuple(clips.shape)}")
+        if clips.shape[3] != self.spec.size:
+            raise ValueError(f"clips are {clips.shape[3]}x{clips.shape[3]}, spec wants {self.spec.size}")
+        if clips.dtype not in (torch.float32, torch.bfloat16):
+            clips = clips.float()
+        return clips.to(self.device).contiguous()
+
+    # ------------------------------------------------------------------ forward
+    def _head(self, feats: torch.Tensor, feats_b, B: int, T: int, keypoints):
+        spec = self.spec
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if spec.temporal == "mean":
+            F = spec.feat_dim
+            pooled = torch.empty(B, F, dtype=torch.float32, device=self.device)
+            L.check(L.lib.asl_mean_t_f32(_ptr(feats), B, T, F, _ptr(pooled), stream), "mean_t")
+            logits = torch.empty(B, spec.num_classes, dtype=torch.float32, device=self.device)
+            L.check(L.lib.asl_head_f32(_ptr(pooled), B, F, _ptr(self._fc_w), _ptr(self._fc_b), spec.num_classes,
+                                       _ptr(logits), stream), "head")
+            return logits
+        return self._temporal(feats, feats_b, B, T, keypoints, stream)
+
+    @torch.no_grad()
+    def forward(self, clips: torch.Tensor, keypoints: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if not self._w:
+            raise RuntimeError("load_state_dict() first (or construct with seed=...)")
+        B, T = clips.shape[:2]
+        if self.spec.keypoints and keypoints is None:
+            raise ValueError(f"spec {self.spec.name} needs keypoints [B,T,21,2]")
+        feats, feats_b = self.frame_features(clips, want_bf16=self.spec.temporal != "mean")
+        return self._head(feats, feats_b, B, T, keypoints)
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def classify_clip(self, frames: torch.Tensor, keypoints: Optional[torch.Tensor] = None, topk: int = 5):
+        """frames uint8 [T,H0,W0,3] or [B,T,H0,W0,3] -> (idx int64 [B,k], prob float32 [B,k])."""
+        if frames.dtype != torch.uint8:
+            raise ValueError("frames must be uint8")
+        if frames.dim() == 4:
+            frames = frames[None]
+            if keypoints is not None and keypoints.dim() == 3:
+                keypoints = keypoints[None]
+        if frames.dim() != 5 or frames.shape[-1] != 3:
+            raise ValueError(f"frames must be [B,T,H0,W0,3], got {tuple(frames.shape)}")
+        frames = frames.to(self.device).contiguous()
+        B, T, H0, W0, _ = frames.shape
+        S = self.spec.size
+        mean = (C.c_float * 3)(*IMAGENET_MEAN)
+        std = (C.c_float * 3)(*IMAGENET_STD)
+        base = frames.data_ptr()
+
+        def fill(c0, n, x0, in_halo, stream):
+            L.check(L.lib.asl_preprocess_u8(C.c_void_p(base + c0 * H0 * W0 * 3), n, H0, W0, S, in_halo, mean, std,
+                                            _ptr(x0), None, stream), "preprocess")
+        feats, feats_b = self._run_backbone(B * T, fill, self.spec.temporal != "mean")
+        logits = self._head(feats, feats_b, B, T, keypoints)
+        k = int(topk)
+        idx = torch.empty(B, k, dtype=torch.int64, device=self.device)
+        prob = torch.empty(B, k, dtype=torch.float32, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(L.lib.asl_softmax_topk(_ptr(logits), B, self.spec.num_classes, k, _ptr(idx), _ptr(prob), stream),
+                "softmax_topk")
+        return idx, prob
+
+    @torch.no_grad()
+    def preprocess(self, frames: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,T,H0,W0,3] -> normalised fp32 clips [B,T,3,S,S] (what forward() takes)."""
+        frames = frames.to(self.device).contiguous()
+        B, T, H0, W0, _ = frames.shape
+        S = self.spec.size
+        out = torch.empty(B, T, 3, S, S, dtype=torch.float32, device=self.device)
+        scratch = torch.empty(B * T, S, S, 4, dtype=torch.bfloat16, device=self.device)
+        mean = (C.c_float * 3)(*IMAGENET_MEAN)
+        std = (C.c_float * 3)(*IMAGENET_STD)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(L.lib.asl_preprocess_u8(_ptr(frames), B * T, H0, W0, S, 0, mean, std, _ptr(scratch), _ptr(out),
+                                        stream), "preprocess")
+        return out
+
+    def workspace_bytes(self) -> int:
+        return 0 if self._plan is None else self._plan["pool"].nbytes() + self._plan["x0"].numel() * 2
+
+
+def init_state_dict(spec: ModelSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init parameters with the names/shapes of `spec` (bench and smoke use this when no
+    checkpoint is given): He-normal convs, non-trivial BatchNorm statistics, uniform linears; all
+    values bf16-representable."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shp in param_shapes(spec).items():
+        if name.endswith("running_var") or (".bn" in name or "downsample.1" in name or ".norm" in name) and name.endswith(".weight"):
+            t = torch.empty(shp).uniform_(0.5, 1.5, generator=g)
+        elif name.endswith("running_mean") or name.endswith(".bias") and len(shp) == 1 and (
+                ".bn" in name or "downsample.1" in name or ".norm" in name):
+            t = torch.empty(shp).normal_(0.0, 0.1, generator=g)
+        elif len(shp) >= 4:
+            fan_out = shp[0]
+            for d in shp[2:]:
+                fan_out *= d
+            t = torch.empty(shp).normal_(0.0, (2.0 / fan_out) ** 0.5, generator=g)
+        elif len(shp) == 2:
+            k = 1.0 / (shp[1] ** 0.5)
+            t = torch.empty(shp).uniform_(-k, k, generator=g)
+        else:
+            t = torch.empty(shp).uniform_(-0.05, 0.05, generator=g)
+        sd[name] = t.to(torch.bfloat16).to(torch.float32)
+    return sd
