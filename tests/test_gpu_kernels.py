@@ -111,7 +111,8 @@ def test_maxpool_exact(gpu):
     x = _bf16(torch.rand(2, 64, 30, 22) * 4)
     ref = F.max_pool2d(x, 3, 2, 1)
     yd = torch.zeros(2, 15 + 2, 11 + 2, 64, dtype=torch.bfloat16, device="cuda")
-    L.check(L.lib.asl_maxpool3x3s2_nhwc(_p(_halo(x, 1)), 2, 30, 22, 64, 1, _p(yd), 1, None))
+    xd = _halo(x, 1)
+    L.check(L.lib.asl_maxpool3x3s2_nhwc(_p(xd), 2, 30, 22, 64, 1, _p(yd), 1, None))
     torch.cuda.synchronize()
     assert torch.equal(_unhalo(yd, 1), ref)
 
@@ -124,13 +125,15 @@ def test_avgpool_mean_head(gpu, c):
     ref = x.mean((2, 3))
     yf = torch.empty(n, c, device="cuda")
     yb = torch.empty(n, c, dtype=torch.bfloat16, device="cuda")
-    L.check(L.lib.asl_avgpool_nhwc(_p(_halo(x, 1)), n, 7, 7, c, 1, _p(yf), _p(yb), c, None))
+    xd = _halo(x, 1)
+    L.check(L.lib.asl_avgpool_nhwc(_p(xd), n, 7, 7, c, 1, _p(yf), _p(yb), c, None))
     pooled = torch.empty(n // t, c, device="cuda")
     L.check(L.lib.asl_mean_t_f32(_p(yf), n // t, t, c, _p(pooled), None))
     w = torch.randn(100, c) / c ** 0.5
     b = torch.randn(100) * 0.1
     logits = torch.empty(n // t, 100, device="cuda")
-    L.check(L.lib.asl_head_f32(_p(pooled), n // t, c, _p(w.cuda()), _p(b.cuda()), 100, _p(logits), None))
+    wd, bd = w.cuda(), b.cuda()          # keep the device copies alive across the async launch
+    L.check(L.lib.asl_head_f32(_p(pooled), n // t, c, _p(wd), _p(bd), 100, _p(logits), None))
     torch.cuda.synchronize()
     torch.testing.assert_close(yf.cpu(), ref, rtol=1e-5, atol=1e-5)
     assert torch.equal(yb.float().cpu(), _bf16(yf.cpu()))
@@ -151,7 +154,8 @@ def test_linear(gpu, m, n, k):
     pc = pack_linear(w, "cuda", bias=b)
     y = torch.empty(m, n, device="cuda")
     p = L.LinearParams(m=m, n=n, k=k, ldx=k, ldy=n, ldres=0, relu=0, out_f32=1, w_rows=pc.w_rows)
-    L.check(L.lib.asl_linear_bf16(C.byref(p), _p(x.cuda().to(torch.bfloat16)), _p(pc.w), None, _p(pc.bias), None, _p(y), None))
+    xd = x.cuda().to(torch.bfloat16)
+    L.check(L.lib.asl_linear_bf16(C.byref(p), _p(xd), _p(pc.w), None, _p(pc.bias), None, _p(y), None))
     torch.cuda.synchronize()
     torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-4)
 
@@ -165,7 +169,8 @@ def test_preprocess_matches_interpolate(gpu, h0, w0, s):
     out = torch.empty(3, 3, s, s, device="cuda")
     mean = (C.c_float * 3)(*O.IMAGENET_MEAN)
     std = (C.c_float * 3)(*O.IMAGENET_STD)
-    L.check(L.lib.asl_preprocess_u8(_p(frames.cuda()), 3, h0, w0, s, 3, mean, std, _p(x0), _p(out), None))
+    fd = frames.cuda()
+    L.check(L.lib.asl_preprocess_u8(_p(fd), 3, h0, w0, s, 3, mean, std, _p(x0), _p(out), None))
     torch.cuda.synchronize()
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
     packed = x0.float().cpu()
@@ -179,7 +184,8 @@ def test_softmax_topk(gpu):
     logits[1, 17] = logits[1, 400] = 50.0          # tie: lower index first
     idx = torch.empty(4, 5, dtype=torch.int64, device="cuda")
     prob = torch.empty(4, 5, device="cuda")
-    L.check(L.lib.asl_softmax_topk(_p(logits.cuda()), 4, 2000, 5, _p(idx), _p(prob), None))
+    ld = logits.cuda()
+    L.check(L.lib.asl_softmax_topk(_p(ld), 4, 2000, 5, _p(idx), _p(prob), None))
     torch.cuda.synchronize()
     rp, ri = F.softmax(logits, -1).topk(5, -1)
     assert idx[1, 0].item() == 17 and idx[1, 1].item() == 400
