@@ -475,7 +475,7 @@ int main(int argc, char** argv) {
             {2, 8, 8, 32, 64, 3, 2, 1, 1, 1, false, true, true, 0, 0},
             {2, 8, 8, 96, 48, 3, 1, 1, 2, 1, false, true, true, 0, 0},
             {2, 7, 7, 512, 512, 3, 1, 1, 1, 1, true, true, true, 0, 0},
-            {5, 7, 7, 256, 100, 1, 1, 0, 0, 0, false, false, true, 0, 0},
+            {5, 7, 7, 256, 104, 1, 1, 0, 0, 0, false, false, true, 0, 0},
             {2, 6, 6, 64, 36, 1, 1, 0, 1, 1, false, true, true, 96, 32},
             {2, 6, 6, 160, 200, 3, 1, 1, 1, 1, false, true, true, 0, 0},
         };

@@ -1,0 +1,120 @@
+// Shared epilogue of the MFMA kernels: scale/bias (BatchNorm), residual add, ReLU, bf16 or fp32
+// store, with the accumulator transposed through a small wave-private LDS stage so that every
+// global access is 16 bytes per lane and 8 consecutive lanes cover one pixel's 64 contiguous
+// channels (full 128-byte lines) instead of the accumulator's native 4-channel granules.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace asl_detail {
+
+struct OutGeom {
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    int M, N;
+    int OW, OHW, ODHW;                 // output grid decomposition of row m
+    long long out_sn, res_sn;
+    int out_sd, out_sh, out_sw, out_off0;
+    int res_sd, res_sh, res_sw, res_off0;
+    int relu, out_f32;
+};
+
+constexpr int kEpiRowBytes(int wtn) { return wtn * 4 + 16; }          // fp32 row + 16 B pad
+constexpr int kEpiWaveBytes(int wtn) { return 16 * kEpiRowBytes(wtn); }
+
+// acc[i][j]: 16x16 tile (pixel fragment i, channel fragment j); lane holds channels 4*(lane>>4)..+3
+// of pixel (lane & 15).  `stage` is this wave's private LDS region of kEpiWaveBytes(FN*16) bytes; the
+// caller guarantees no other wave still reads the LDS it overlays.
+template <int FM, int FN>
+__device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char* stage, const OutGeom& g,
+                                               int m_wave0, int ch_wave0, int lane) {
+    constexpr int WTN = FN * 16;
+    constexpr int ROWB = kEpiRowBytes(WTN);
+    constexpr int G8 = WTN / 8;                  // 8-channel groups per pixel row of the wave tile
+    constexpr int PPI = 64 / G8;                 // pixels covered per pass of 64 lanes
+    constexpr int PASSES = 16 / PPI;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int g8 = lane % G8, pr0 = lane / G8;
+    const int ch = ch_wave0 + g8 * 8;
+    const bool full = ch + 7 < g.N;
+    f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (full) {
+        if (g.scale) { s0 = *(const f32x4*)(g.scale + ch); s1 = *(const f32x4*)(g.scale + ch + 4); }
+        if (g.bias) { b0 = *(const f32x4*)(g.bias + ch); b1 = *(const f32x4*)(g.bias + ch + 4); }
+    }
+    // output / residual element offsets of this lane's (fragment, pass) pixels; every residual load is
+    // issued here, ahead of the staging loop, so their latencies overlap instead of adding up
+    long long oe[FM][PASSES], re[FM][PASSES];
+    bool ok[FM][PASSES];
+    bf16x8 r8[FM][PASSES];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int m = m_wave0 + i * 16 + ps * PPI + pr0;
+            ok[i][ps] = m < g.M && ch < g.N;
+            const int mm = m < g.M ? m : g.M - 1;
+            const int n = mm / g.ODHW, r1 = mm - n * g.ODHW;
+            const int d = r1 / g.OHW, r2 = r1 - d * g.OHW;
+            const int h = r2 / g.OW, w_ = r2 - h * g.OW;
+            oe[i][ps] = (long long)n * g.out_sn + (long long)d * g.out_sd + (long long)h * g.out_sh +
+                        (long long)w_ * g.out_sw + g.out_off0 + ch;
+            re[i][ps] = 0;
+            r8[i][ps] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (g.res) {
+                re[i][ps] = (long long)n * g.res_sn + (long long)d * g.res_sd + (long long)h * g.res_sh +
+                            (long long)w_ * g.res_sw + g.res_off0 + ch;
+                if (ok[i][ps] && full) r8[i][ps] = *(const bf16x8*)(g.res + 2 * re[i][ps]);
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) *(f32x4*)(stage + fr * ROWB + (j * 16 + fq * 4) * 4) = acc[i][j];
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int pr = ps * PPI + pr0;
+            f32x4 v0 = *(const f32x4*)(stage + pr * ROWB + g8 * 32);
+            f32x4 v1 = *(const f32x4*)(stage + pr * ROWB + g8 * 32 + 16);
+            if (!ok[i][ps]) continue;
+            const long long o = oe[i][ps];
+            if (full) {
+                v0 = v0 * s0 + b0;
+                v1 = v1 * s1 + b1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] += bf16_to_f32(r8[i][ps][e]);
+                    v1[e] += bf16_to_f32(r8[i][ps][4 + e]);
+                }
+                if (g.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                }
+                if (g.out_f32) {
+                    *(f32x4*)(g.y + 4 * o) = v0;
+                    *(f32x4*)(g.y + 4 * o + 16) = v1;
+                } else {
+                    bf16x8 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ov[e] = f32_to_bf16(v0[e]); ov[4 + e] = f32_to_bf16(v1[e]); }
+                    *(bf16x8*)(g.y + 2 * o) = ov;
+                }
+            } else {
+                for (int e = 0; e < 8 && ch + e < g.N; ++e) {
+                    float t = e < 4 ? v0[e & 3] : v1[e & 3];
+                    if (g.scale) t *= g.scale[ch + e];
+                    if (g.bias) t += g.bias[ch + e];
+                    if (g.res) t += bf16_to_f32(*(const short*)(g.res + 2 * (re[i][ps] + e)));
+                    if (g.relu) t = fmaxf(t, 0.f);
+                    if (g.out_f32) *(float*)(g.y + 4 * (o + e)) = t;
+                    else *(short*)(g.y + 2 * (o + e)) = f32_to_bf16(t);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace asl_detail

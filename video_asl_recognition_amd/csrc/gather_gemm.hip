@@ -14,6 +14,9 @@
 
 #include "asl_hip.h"
 #include "common.h"
+#include "epilogue.h"
+#include "patch_args.h"
+#include <stdlib.h>
 
 namespace asl_detail {
 
@@ -199,65 +202,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
         buf ^= 1;
     }
 
-    // ---- epilogue: lane holds channels ch..ch+3 of pixel (lane & 15) per tile -----------------
-    const int chb = tn * BN + wn * WTN + fq * 4;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + fr;
-        if (m >= a.M) continue;
-        const int n = m / a.ODHW, r1 = m - n * a.ODHW;
-        const int d = r1 / a.OHW, r2 = r1 - d * a.OHW;
-        const int h = r2 / a.OW, w_ = r2 - h * a.OW;
-        const long long oe = (long long)n * a.out_sn + (long long)d * a.out_sd + (long long)h * a.out_sh +
-                             (long long)w_ * a.out_sw + a.out_off0;
-        long long re = 0;
-        if (a.res)
-            re = (long long)n * a.res_sn + (long long)d * a.res_sd + (long long)h * a.res_sh +
-                 (long long)w_ * a.res_sw + a.res_off0;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int ch = chb + j * 16;
-            if (ch >= a.N) continue;
-            f32x4 v = acc[i][j];
-            if (ch + 3 < a.N) {
-                if (a.scale) {
-                    const f32x4 s4 = *(const f32x4*)(a.scale + ch);
-                    v *= s4;
-                }
-                if (a.bias) {
-                    const f32x4 b4 = *(const f32x4*)(a.bias + ch);
-                    v += b4;
-                }
-                if (a.res) {
-                    const bf16x4 r4 = *(const bf16x4*)(a.res + 2 * (re + ch));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bf16_to_f32(r4[e]);
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (a.out_f32) {
-                    *(f32x4*)(a.y + 4 * (oe + ch)) = v;
-                } else {
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(v[e]);
-                    *(bf16x4*)(a.y + 2 * (oe + ch)) = o;
-                }
-            } else {
-                for (int e = 0; e < 4 && ch + e < a.N; ++e) {
-                    float t = v[e];
-                    if (a.scale) t *= a.scale[ch + e];
-                    if (a.bias) t += a.bias[ch + e];
-                    if (a.res) t += bf16_to_f32(*(const short*)(a.res + 2 * (re + ch + e)));
-                    if (a.relu) t = fmaxf(t, 0.f);
-                    if (a.out_f32) *(float*)(a.y + 4 * (oe + ch + e)) = t;
-                    else *(short*)(a.y + 2 * (oe + ch + e)) = f32_to_bf16(t);
-                }
-            }
-        }
-    }
+    // ---- epilogue (the loop's last barrier guarantees every wave is done reading the stages) -----
+    OutGeom g;
+    g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = a.M; g.N = a.N;
+    g.OW = a.OW; g.OHW = a.OHW; g.ODHW = a.ODHW;
+    g.out_sn = a.out_sn; g.out_sd = a.out_sd; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
+    g.res_sn = a.res_sn; g.res_sd = a.res_sd; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
+    g.relu = a.relu; g.out_f32 = a.out_f32;
+    static_assert(NW * kEpiWaveBytes(WTN) <= 2 * BUF, "epilogue stage does not fit the K-loop LDS");
+    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(WTN), g, m0 + wm * WTM, tn * BN + wn * WTN, lane);
 #endif
 }
 
@@ -298,12 +251,15 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
     const long long wk = (long long)p->kd * p->kh * p->kw * p->ck;
     if (p->w_rows < p->cout || (p->w_rows & 127) || wk * p->w_rows * 2 > 0x7fffffffLL) return ASL_EINVAL;
     // 16-byte alignment of every LDS-DMA source and 8-byte alignment of epilogue vectors
-    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)res & 7)) return ASL_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)res & 15)) return ASL_EINVAL;
     if (((uintptr_t)scale & 15) || ((uintptr_t)bias & 15)) return ASL_EINVAL;
     if ((p->in.sn & 7) || (p->in.sd & 7) || (p->in.sh & 7) || (p->in.sw & 7) || (p->in.off0 & 7)) return ASL_EINVAL;
     if ((p->tap_sd & 7) || (p->tap_sh & 7) || (p->tap_sw & 7)) return ASL_EINVAL;
-    if ((p->out.sn & 3) || (p->out.sd & 3) || (p->out.sh & 3) || (p->out.sw & 3) || (p->out.off0 & 3)) return ASL_EINVAL;
-    if (res && ((p->res.sn & 3) || (p->res.sd & 3) || (p->res.sh & 3) || (p->res.sw & 3) || (p->res.off0 & 3)))
+    // epilogue vectors: 8 bf16 or 2 x 4 fp32 per lane, 16-byte aligned
+    const int oal = p->out_f32 ? 3 : 7;
+    if ((p->out.sn & oal) || (p->out.sd & oal) || (p->out.sh & oal) || (p->out.sw & oal) || (p->out.off0 & oal))
+        return ASL_EINVAL;
+    if (res && ((p->res.sn & 7) || (p->res.sd & 7) || (p->res.sh & 7) || (p->res.sw & 7) || (p->res.off0 & 7)))
         return ASL_EINVAL;
     // bounds: last input element read, last output / residual element touched
     const long long tap_ext = (long long)(p->kd - 1) * p->tap_sd + (long long)(p->kh - 1) * p->tap_sh +
@@ -336,6 +292,24 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
     a.tiles_m = a.tiles_n = 0;
 
     hipStream_t s = (hipStream_t)stream;
+    // 3x3 / stride 1 / pad 1 on a halo'd NHWC tensor with C % 64 == 0: the LDS-resident-patch kernel
+    if (p->kd == 1 && p->kh == 3 && p->kw == 3 && p->od == 1 && (p->ck & 63) == 0 && !p->out_f32 &&
+        p->tap_sw == p->ck && p->in.sw == p->ck && p->in.sh == p->tap_sh && p->tap_sh % p->ck == 0 &&
+        p->in.sn % p->tap_sh == 0 && !getenv("ASL_NO_PATCH_CONV")) {
+        const int C = p->ck, Wp = p->tap_sh / C, Hp = (int)(p->in.sn / p->tap_sh);
+        const int halo = (Wp - p->ow) / 2;
+        if (halo >= 1 && Wp == p->ow + 2 * halo && Hp == p->oh + 2 * halo &&
+            p->in.off0 == ((halo - 1) * Wp + (halo - 1)) * C && patch_conv_fits(p->nb, p->oh, p->ow, halo)) {
+            PatchArgs b;
+            b.x = a.x; b.w = a.w; b.scale = a.scale; b.bias = a.bias; b.res = a.res; b.y = a.y;
+            b.M = a.M; b.N = a.N; b.H = p->oh; b.W = p->ow; b.Hp = Hp; b.Wp = Wp; b.in_halo = halo;
+            b.C = C; b.nchunks = C / 64; b.wk = a.wk; b.x_bytes = a.x_bytes; b.w_bytes = a.w_bytes;
+            b.out_sn = a.out_sn; b.out_sh = a.out_sh; b.out_sw = a.out_sw; b.out_off0 = a.out_off0;
+            b.res_sn = a.res_sn; b.res_sh = a.res_sh; b.res_sw = a.res_sw; b.res_off0 = a.res_off0;
+            b.relu = a.relu; b.tiles_m = b.tiles_n = 0; b.OW = a.OW; b.OHW = a.OHW; b.ODHW = a.ODHW;
+            return launch_conv3x3_patch(b, s);
+        }
+    }
     if (p->ck % 64 == 0) {
         a.ksteps_per_tap = p->ck / 64;
         if (p->cout <= 64) return launch<128, 64, 64, 2, 2>(a, s);

@@ -1,0 +1,32 @@
+// Kernel arguments of the LDS-resident-patch 3x3 convolution (conv3x3_patch.hip), filled by the
+// gather-GEMM entry point when a request has that shape.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace asl_detail {
+
+struct PatchArgs {
+    const char* x;
+    const char* w;
+    const float* scale;
+    const float* bias;
+    const char* res;
+    char* y;
+    int M, N;              // output pixels (n*H*W), output channels
+    int H, W;              // output = input spatial size
+    int Hp, Wp, in_halo;   // halo'd input geometry
+    int C, nchunks;        // input channels, C / 64
+    int wk;                // packed K per weight row (9*C)
+    long long x_bytes, w_bytes;
+    long long out_sn, res_sn;
+    int out_sh, out_sw, out_off0;
+    int res_sh, res_sw, res_off0;
+    int relu;
+    int OW, OHW, ODHW;
+    int tiles_m, tiles_n;
+};
+
+bool patch_conv_fits(int n, int h, int w, int in_halo);
+int launch_conv3x3_patch(const PatchArgs& a, hipStream_t stream);
+
+}  // namespace asl_detail
