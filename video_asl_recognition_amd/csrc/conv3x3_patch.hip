@@ -5,13 +5,13 @@
 // Here a workgroup owns 256 consecutive output pixels (row-major over image, row, column;
 // tiles may straddle rows and images), copies the contiguous range of halo'd input pixels
 // those outputs touch into LDS ONCE per 64-channel chunk, and reads all nine taps' pixel
-// fragments from that patch at a per-tap constant offset.  Only the weight tile of each
-// (chunk, tap) step still streams through a double-buffered LDS-DMA stage, and the next
-// chunk's patch is fetched in ninths alongside it.
+// fragments from that patch at a per-tap constant offset.  Only the 64x64 weight tile of each
+// (chunk, tap) step still streams, through a 3-deep LDS-DMA ring with counted waits.
 //
 // MFMA orientation, epilogue and weight packing are those of gather_gemm.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "asl_hip.h"
 #include "common.h"
@@ -20,29 +20,26 @@
 
 namespace asl_detail {
 
-constexpr int kPatchPixels = 448;             // LDS patch capacity in pixels (x 128 B per 64-channel chunk)
+// LDS budget of one workgroup: patch (kPatchPixels x 128 B, one 64-channel chunk) + kStages weight
+// stages of 64 rows x 128 B = 55,296 + 24,576 = 78 KiB, so two workgroups share a CU's 160 KiB and
+// cover each other's prologue, epilogue and patch reloads.
+constexpr int kPatchPixels = 432;
 constexpr int kPatchBytes = kPatchPixels * 128;
+constexpr int kStages = 3;                    // weight ring depth: prefetch distance 2
 
-__device__ __forceinline__ void wait_vm0_p() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// BN: output channels per workgroup; WGN: waves along channels (4 waves along pixels always)
-template <int BN, int WGN>
-__global__ __launch_bounds__(4 * WGN * 64) void conv3x3_patch_kernel(const PatchArgs a) {
+// 4 waves; workgroup tile = up to 256 pixel slots x 64 output channels; each wave 64 slots x 64 channels
+__global__ __launch_bounds__(256) void conv3x3_patch_kernel(const PatchArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BM = 256, WGM = 4, NW = WGM * WGN;
-    constexpr int WTM = BM / WGM, WTN = BN / WGN;
-    constexpr int FM = WTM / 16, FN = WTN / 16;
-    constexpr int W_BYTES = BN * 128;                 // one (chunk, tap) weight stage: BN rows x 64 channels
-    constexpr int W_PW = W_BYTES / 1024 / NW;         // LDS-DMA instructions per wave per stage
-    static_assert(W_PW >= 1 && W_PW * NW * 1024 == W_BYTES, "weight stage / wave mismatch");
+    constexpr int BN = 64, NW = 4;
+    constexpr int FM = 4, FN = 4;
+    constexpr int W_BYTES = BN * 128;                 // one (chunk, tap) weight stage
+    constexpr int W_PW = W_BYTES / 1024 / NW;         // LDS-DMA instructions per wave per stage (2)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int npbuf = a.nchunks > 1 ? 2 : 1;
-    char* const wst = smem + npbuf * kPatchBytes;      // weight stages follow the patch buffers
+    char* const wst = smem + kPatchBytes;              // weight ring follows the patch
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
 
     int lbid;
     {
@@ -51,7 +48,15 @@ __global__ __launch_bounds__(4 * WGN * 64) void conv3x3_patch_kernel(const Patch
         lbid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int tn = lbid % a.tiles_n, tm = lbid / a.tiles_n;
-    const int m0 = tm * BM;
+    const int m0 = tm * a.bmv;                         // bmv <= 256 valid pixel slots per tile
+    // Two workgroups share a CU.  Dispatched together they would load, compute and store in lockstep
+    // and leave HBM idle during the K loops; delaying the second resident set once, by about half a
+    // tile, keeps one workgroup's epilogue under the other's MFMA phase.  Speed only: any placement
+    // is correct.
+    if (a.stagger_ticks > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(8);
+    }
     const int HW = a.H * a.W;
 
     // centre pixel (in halo'd, image-major pixel units) of output pixel m
@@ -60,9 +65,9 @@ __global__ __launch_bounds__(4 * WGN * 64) void conv3x3_patch_kernel(const Patch
         const int y = r1 / a.W, x = r1 - y * a.W;
         return ((long long)n * a.Hp + y + a.in_halo) * a.Wp + x + a.in_halo;
     };
-    const int mlast = (m0 + BM - 1 < a.M ? m0 + BM - 1 : a.M - 1);
+    const int mend = (m0 + a.bmv < a.M ? m0 + a.bmv : a.M);           // one past this tile's last pixel
     const long long P0 = centre(m0) - a.Wp - 1;                       // first pixel of the patch
-    const int NP = (int)(centre(mlast) + a.Wp + 1 - P0) + 1;          // pixels in the patch (<= kPatchPixels)
+    const int NP = (int)(centre(mend - 1) + a.Wp + 1 - P0) + 1;       // pixels in the patch (<= kPatchPixels)
     const int NPI = (NP + 7) >> 3;                                    // 8 pixels per DMA instruction
 
     // ---- DMA descriptors ---------------------------------------------------------------------
@@ -75,9 +80,9 @@ __global__ __launch_bounds__(4 * WGN * 64) void conv3x3_patch_kernel(const Patch
     const unsigned wrec = (unsigned)(a.w_bytes - 2LL * (tn * BN) * a.wk);
     __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wrec, 0x00020000);
 
-    // patch DMA: instruction i covers patch pixels 8i..8i+7; slot (p, c') holds chunk c' ^ ((p>>1)&7)
-    // lane -> pixel 8i + lane/8, so (p>>1)&7 = ((lane>>4) + 4i) & 7: two per-lane variants (i even / odd)
-    // (fq + 4*(i&1)) & 7 == fq | ((i&1) << 2): the odd-i variant is the even one with byte-offset bit 6 flipped
+    // patch DMA: instruction i covers patch pixels 8i..8i+7; slot (p, c') holds chunk c' ^ ((p>>1)&7).
+    // lane -> pixel 8i + lane/8, so (p>>1)&7 = (lane>>4) | ((i&1) << 2): the odd-i offset is the even-i
+    // one with byte-offset bit 6 flipped
     const unsigned pvoff0 = (unsigned)((lane >> 3) * pix_bytes + 16 * ((lane & 7) ^ (lane >> 4)));
     unsigned wvoff[W_PW];
 #pragma unroll
@@ -85,16 +90,18 @@ __global__ __launch_bounds__(4 * WGN * 64) void conv3x3_patch_kernel(const Patch
         const int row = (wave * W_PW + i) * 8 + (lane >> 3);
         wvoff[i] = (unsigned)(2 * row * a.wk + 16 * ((lane & 7) ^ ((row >> 1) & 7)));
     }
-
-    auto dma_patch = [&](int i, int chunk, int pbuf) {      // i, chunk, pbuf wave-uniform
-        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(i * 8 * pix_bytes + chunk * 128));
-        char* dst = smem + pbuf * kPatchBytes + i * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16,
-                                                 pvoff0 ^ ((unsigned)(i & 1) << 6), so, 0, 0);
+    auto dma_patch = [&](int chunk) {
+        for (int i = wave; i < NPI; i += NW) {
+            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(i * 8 * pix_bytes + chunk * 128));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(smem + i * 1024), 16,
+                                                     pvoff0 ^ ((unsigned)(i & 1) << 6), so, 0, 0);
+        }
     };
-    auto dma_weights = [&](int chunk, int tap, int wbuf) {
+    const int nsteps = a.nchunks * 9;
+    auto dma_weights = [&](int s) {                    // step s = chunk * 9 + tap -> ring slot s % kStages
+        const int chunk = s / 9, tap = s - 9 * chunk;
         const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(2 * (tap * a.C + chunk * 64)));
-        char* dst = wst + wbuf * W_BYTES + wave * (W_PW * 1024);
+        char* dst = wst + (s % kStages) * W_BYTES + wave * (W_PW * 1024);
 #pragma unroll
         for (int i = 0; i < W_PW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
@@ -106,14 +113,14 @@ __global__ __launch_bounds__(4 * WGN * 64) void conv3x3_patch_kernel(const Patch
     int pc[FM];                                   // patch-local centre pixel of this lane's pixel, per fragment
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        int m = m0 + wm * WTM + i * 16 + fr;
-        m = m < a.M ? m : a.M - 1;                // tail slots compute a valid pixel again; never stored
+        int m = m0 + wave * 64 + i * 16 + fr;
+        m = m < mend ? m : mend - 1;              // idle slots recompute the tile's last pixel; never stored
         pc[i] = (int)(centre(m) - P0);
     }
     int wrd[FN][2];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const int row = wn * WTN + j * 16 + fr;
+        const int row = j * 16 + fr;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) wrd[j][kk] = row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
     }
@@ -124,100 +131,81 @@ __global__ __launch_bounds__(4 * WGN * 64) void conv3x3_patch_kernel(const Patch
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: whole patch of chunk 0 + weights of (chunk 0, tap 0) -----------------------
-    for (int i = wave; i < NPI; i += NW) dma_patch(i, 0, 0);
-    dma_weights(0, 0, 0);
-    wait_vm0_p();
-    __syncthreads();
+    // ---- prologue: patch of chunk 0, weights of steps 0 and 1 ----------------------------------
+    // Waits are counted: vmcnt(W_PW) retires everything but the youngest weight stage, so one stage stays
+    // in flight across every barrier.  The barrier is raw (inside the asm) so hipcc adds no vmcnt(0).
+    dma_patch(0);
+    dma_weights(0);
+    if (nsteps > 1) {
+        dma_weights(1);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(W_PW) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 
-    int step = 0;
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const int pbuf = chunk & 1;
-        const char* patch = smem + pbuf * kPatchBytes;
+    int tap = 0, chunk = 0;
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap, ++step) {
-            // prefetch: next step's weights, and a ninth of the next chunk's patch
-            const int ntap = tap == 8 ? 0 : tap + 1, nchunk = tap == 8 ? chunk + 1 : chunk;
+    for (int s = 0; s < nsteps; ++s) {
 #if !defined(ASL_ABL_NODMA)
-            if (nchunk < a.nchunks) dma_weights(nchunk, ntap, (step + 1) & 1);
-            if (chunk + 1 < a.nchunks) {
-                const int i = tap * NW + wave;
-                if (i < NPI) dma_patch(i, chunk + 1, pbuf ^ 1);
-                if (tap == 8)                                  // NW * 9 >= 56 instructions except for 4-wave blocks
-                    for (int i2 = 9 * NW + wave; i2 < NPI; i2 += NW) dma_patch(i2, chunk + 1, pbuf ^ 1);
+        if (s + 2 < nsteps) dma_weights(s + 2);       // its ring slot was last read in step s-1
+#endif
+        const int r = tap / 3, q = tap - 3 * r;
+        const int toff = (r - 1) * a.Wp + (q - 1);
+        const char* wb = wst + (s % kStages) * W_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 xf[FM], wf[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int p = pc[i] + toff;
+                xf[i] = *(const bf16x8*)(smem + p * 128 + (((kk * 4 + fq) ^ ((p >> 1) & 7)) << 4));
             }
-#endif
-            const int r = tap / 3, q = tap - 3 * r;
-            const int toff = (r - 1) * a.Wp + (q - 1);
-            const char* wb = wst + (step & 1) * W_BYTES;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 xf[FM], wf[FN];
+            for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(wb + wrd[j][kk]);
 #pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int p = pc[i] + toff;
-#if defined(ASL_ABL_NOLDS)
-                    xf[i] = bf16x8{(short)p, 1, 2, 3, 4, 5, 6, 7};
-#else
-                    xf[i] = *(const bf16x8*)(patch + p * 128 + (((kk * 4 + fq) ^ ((p >> 1) & 7)) << 4));
-#endif
-                }
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-#if defined(ASL_ABL_NOLDS)
-                    wf[j] = bf16x8{(short)wrd[j][kk], 1, 2, 3, 4, 5, 6, 7};
+#if defined(ASL_ABL_NOMFMA)
+                    asm volatile("" ::"v"(wf[j]), "v"(xf[i]));
 #else
-                    wf[j] = *(const bf16x8*)(wb + wrd[j][kk]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
 #endif
                 }
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-#if defined(ASL_ABL_NOMFMA)
-                        asm volatile("" ::"v"(wf[j]), "v"(xf[i]));
-#else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-#endif
-                    }
-            }
-            wait_vm0_p();
-#if !defined(ASL_ABL_NOBAR)
-            __syncthreads();
-#endif
         }
+        if (++tap == 9) {
+            tap = 0;
+            ++chunk;
+            if (chunk < a.nchunks) {
+                // next 64-channel chunk: every wave is done with the patch after this barrier; reload it
+                // (the other resident workgroup covers the bubble), weights in flight keep flying
+                asm volatile("s_barrier" ::: "memory");
+                dma_patch(chunk);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                continue;
+            }
+        }
+        if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(W_PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
 #if defined(ASL_ABL_NOEPI)
     if (a.M > 0) { if (acc[0][0][0] == 123.456f) a.y[0] = 1; return; }
 #endif
 
-    // ---- epilogue: the staging LDS overlays the patch buffer; the loop's last barrier frees it -----
+    // ---- epilogue: the staging LDS overlays the patch; the loop's last barrier frees it ------------
     OutGeom g;
-    g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = a.M; g.N = a.N;
+    g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = mend; g.N = a.N;
     g.OW = a.OW; g.OHW = a.OHW; g.ODHW = a.ODHW;
     g.out_sn = a.out_sn; g.out_sd = 0; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
     g.res_sn = a.res_sn; g.res_sd = 0; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
     g.relu = a.relu; g.out_f32 = 0;
-    static_assert(NW * kEpiWaveBytes(WTN) <= kPatchBytes, "epilogue stage does not fit the patch buffer");
-    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(WTN), g, m0 + wm * WTM, tn * BN + wn * WTN, lane);
+    static_assert(NW * kEpiWaveBytes(FN * 16) <= kPatchBytes, "epilogue stage does not fit the patch buffer");
+    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(FN * 16), g, m0 + wave * 64, tn * BN, lane);
 #endif
 }
 
-template <int BN, int WGN>
-int launch_patch(PatchArgs a, hipStream_t stream) {
-    a.tiles_m = (a.M + 255) / 256;
-    a.tiles_n = (a.N + BN - 1) / BN;
-    const int lds = (a.nchunks > 1 ? 2 : 1) * kPatchBytes + 2 * BN * 128;
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel<BN, WGN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WGN>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(4 * WGN * 64), lds,
-                       stream, a);
-    return (int)hipGetLastError();
-}
-
-// Can the patch kernel run this conv?  (3x3, stride 1, pad 1, C % 64 == 0, every tile's patch fits.)
-bool patch_conv_fits(int n, int h, int w, int in_halo) {
+namespace {
+long long max_patch_pixels(int n, int h, int w, int in_halo, int bmv) {
     const int hp = h + 2 * in_halo, wp = w + 2 * in_halo;
     const long long M = (long long)n * h * w, hw = (long long)h * w;
     auto centre = [&](long long m) {
@@ -225,18 +213,46 @@ bool patch_conv_fits(int n, int h, int w, int in_halo) {
         const long long y = r1 / w, x = r1 - y * w;
         return (img * hp + y + in_halo) * wp + x + in_halo;
     };
-    const long long tiles = (M + 255) / 256;
+    const long long tiles = (M + bmv - 1) / bmv;
     const long long scan = tiles < hw ? tiles : hw;      // the tile/image phase repeats within h*w tiles
+    long long mx = 0;
     for (long long t = 0; t < scan; ++t) {
-        const long long m0 = t * 256, ml = (m0 + 255 < M ? m0 + 255 : M - 1);
-        if (centre(ml) - centre(m0) + 2 * wp + 3 > kPatchPixels) return false;
+        const long long m0 = t * bmv, ml = (m0 + bmv - 1 < M ? m0 + bmv - 1 : M - 1);
+        const long long np = centre(ml) - centre(m0) + 2 * wp + 3;
+        mx = np > mx ? np : mx;
     }
-    return true;
+    return mx;
+}
+}  // namespace
+
+// Pixel slots per tile for this geometry (0 = the patch kernel cannot run it): 256 consecutive pixels
+// when their patch always fits; else whole images; else whole rows that tile an image exactly.
+int patch_conv_tile(int n, int h, int w, int in_halo) {
+    if (max_patch_pixels(n, h, w, in_halo, 256) <= kPatchPixels) return 256;
+    const int hw = h * w;
+    if (hw <= 256) {
+        const int b = 256 / hw * hw;
+        if (max_patch_pixels(n, h, w, in_halo, b) <= kPatchPixels) return b;
+    }
+    for (int k = 256 / w; k >= 1; --k)
+        if (h % k == 0 && k * w * 4 >= 256 * 3 && max_patch_pixels(n, h, w, in_halo, k * w) <= kPatchPixels) return k * w;
+    return 0;
 }
 
-int launch_conv3x3_patch(const PatchArgs& a, hipStream_t stream) {
-    if (a.N <= 64) return launch_patch<64, 1>(a, stream);
-    return launch_patch<128, 2>(a, stream);
+int launch_conv3x3_patch(PatchArgs a, hipStream_t stream) {
+    a.tiles_m = (a.M + a.bmv - 1) / a.bmv;
+    a.tiles_n = (a.N + 63) / 64;
+    // 100 MHz ticks: ~0.2 us per K step is half of a tile's measured duration; only worth it when the
+    // grid runs for many rounds of 512 resident workgroups
+    a.stagger_ticks = 0;
+    if ((long long)a.tiles_m * a.tiles_n >= 6 * 512 && !getenv("ASL_NO_STAGGER")) a.stagger_ticks = 20 * a.nchunks * 9 + 200;
+    if (const char* e = getenv("ASL_STAGGER_TICKS")) a.stagger_ticks = atoi(e);
+    int lds = kPatchBytes + kStages * 64 * 128;
+    if (const char* e2 = getenv("ASL_PATCH_LDS_PAD")) lds += atoi(e2);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(conv3x3_patch_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), lds, stream, a);
+    return (int)hipGetLastError();
 }
 
 }  // namespace asl_detail

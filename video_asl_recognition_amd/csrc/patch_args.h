@@ -16,6 +16,7 @@ struct PatchArgs {
     int H, W;              // output = input spatial size
     int Hp, Wp, in_halo;   // halo'd input geometry
     int C, nchunks;        // input channels, C / 64
+    int bmv;               // valid pixel slots per 256-slot tile
     int wk;                // packed K per weight row (9*C)
     long long x_bytes, w_bytes;
     long long out_sn, res_sn;
@@ -24,9 +25,10 @@ struct PatchArgs {
     int relu;
     int OW, OHW, ODHW;
     int tiles_m, tiles_n;
+    int stagger_ticks;     // one-time start delay (100 MHz ticks) of the second resident workgroup set
 };
 
-bool patch_conv_fits(int n, int h, int w, int in_halo);
-int launch_conv3x3_patch(const PatchArgs& a, hipStream_t stream);
+int patch_conv_tile(int n, int h, int w, int in_halo);
+int launch_conv3x3_patch(PatchArgs a, hipStream_t stream);
 
 }  // namespace asl_detail
