@@ -62,7 +62,7 @@ typedef struct asl_geom {
  *   w      packed bf16 [w_rows][wk], wk = kd*kh*kw*ck, w_rows = cout rounded up to 128,
  *          rows >= cout zero.
  *   scale  fp32 [cout] or NULL (1.0);  bias fp32 [cout] or NULL (0.0)
- *   res    bf16 residual or NULL;      y bf16 (out_f32 == 0) or fp32 (out_f32 == 1)
+ *   res    residual (bf16, or fp32 if res_f32) or NULL;  y bf16 (out_f32 == 0) or fp32 (out_f32 == 1)
  *   *_elems  allocation sizes in elements, used to reject out-of-bounds geometry.       */
 typedef struct asl_gemm_params {
     int32_t nb, od, oh, ow;          /* output grid; M = nb*od*oh*ow            */
@@ -73,6 +73,7 @@ typedef struct asl_gemm_params {
     asl_geom in, out, res;
     int32_t relu;
     int32_t out_f32;
+    int32_t res_f32;
     int32_t w_rows;
     int64_t x_elems, y_elems, res_elems;
 } asl_gemm_params;
@@ -133,11 +134,12 @@ int asl_conv3d_ndhwc_bf16(const asl_conv3d_params* p, const void* x, const void*
                           const float* scale, const float* bias, void* y, asl_stream_t stream);
 
 /* nn.Linear on bf16 rows: y[m][n] = act(scale[n] * sum_k x[m][k] w[n][k] + bias[n] (+ res)).
- * x bf16 [m][ldx] (k % 32 == 0, ldx >= k), w packed [w_rows][k], y bf16 or fp32 [m][ldy]. */
+ * x bf16 [m][ldx] (k % 32 == 0, ldx >= k), w packed [w_rows][k], y bf16 or fp32 [m][ldy],
+ * res bf16 or (res_f32) fp32 [m][ldres]. */
 typedef struct asl_linear_params {
     int32_t m, n, k;
     int32_t ldx, ldy, ldres;
-    int32_t relu, out_f32;
+    int32_t relu, out_f32, res_f32;
     int32_t w_rows;
 } asl_linear_params;
 
@@ -175,11 +177,13 @@ typedef struct asl_pool3d_params {
 } asl_pool3d_params;
 int asl_maxpool3d_ndhwc(const asl_pool3d_params* p, const void* x, void* y, asl_stream_t stream);
 
-/* x.mean((2,3)) per frame: halo'd NHWC bf16 [n][h+2*halo][w+2*halo][c] -> fp32 [n][c] (and, if
- * y_bf16 != NULL, the same values rounded to bf16 with row pitch ld_bf16, as GEMM input).
+/* x.mean((2,3)) per frame: halo'd NHWC bf16 [n][h+2*halo][w+2*halo][c] -> fp32 [n][c] and, if
+ * y_bf16 != NULL, a bf16 copy with row pitch ld_bf16 for use as a GEMM operand: columns [0,c) hold
+ * bf16(v); if lo_off > 0, columns [lo_off, lo_off+c) hold bf16(v - bf16(v)), so a GEMM over both
+ * column blocks with the weight matrix repeated sees v to ~16 mantissa bits.
  * c/8 must be a power of two below 256 or a multiple of 256. */
 int asl_avgpool_nhwc(const void* x, int n, int h, int w, int c, int halo,
-                     float* y_f32, void* y_bf16, int ld_bf16, asl_stream_t stream);
+                     float* y_f32, void* y_bf16, int ld_bf16, int lo_off, asl_stream_t stream);
 
 /* y[r][c] = mean over t of x[r][t][c]  (fp32 [rows][t][c] -> fp32 [rows][c]) */
 int asl_mean_t_f32(const float* x, int rows, int t, int c, float* y, asl_stream_t stream);
@@ -192,6 +196,52 @@ int asl_head_f32(const float* x, int m, int f, const float* w, const float* b, i
  * k <= 16.  Ties resolve to the lower class index. */
 int asl_softmax_topk(const float* logits, int m, int c, int k, int64_t* idx, float* prob,
                      asl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Temporal encoders
+ * ---------------------------------------------------------------------------------- */
+
+/* One layer of nn.LSTM(bidirectional=True, batch_first=True), zero initial state, PyTorch gate
+ * order (i, f, g, o).  The input projection is done beforehand by asl_linear_bf16 into
+ *   gx fp32 [batch*t][ld_gx]: columns [0,4H) = x W_ih^T + b_ih + b_hh of the forward direction,
+ *                             columns [4H,8H) the same for the reverse direction;
+ *   w_hh bf16 [2][4H][H] (forward, reverse).
+ * Writes y bf16 [batch*t][ld_y] (forward h in columns [0,H), reverse h, aligned to the input time
+ * index, in [H,2H); if split_y, additionally bf16(h - bf16(h)) in columns [2H,4H), the low halves for
+ * a split-precision GEMM operand) and, if ysum != NULL, ysum fp32 [batch][2H] = sum over t of ysum_scale * h (the
+ * temporal mean when ysum_scale = 1/t).  state: caller scratch of 6*batch*H floats (h ping, h pong, c; zeroed here).
+ * The recurrence runs in fp32; one launch per time step on `stream`. */
+typedef struct asl_lstm_params {
+    int32_t batch, t, hidden;
+    int32_t ld_gx, ld_y;
+    int32_t split_y;
+    float ysum_scale;       /* each h is multiplied by this before it is added to ysum (1/t: mean) */
+} asl_lstm_params;
+
+int asl_lstm_bidir_layer(const asl_lstm_params* p, const float* gx, const void* w_hh, void* y_bf16,
+                         float* ysum, float* state, asl_stream_t stream);
+
+/* nn.LayerNorm(d) over fp32 rows: y = (x - mean) / sqrt(var + eps) * gamma + beta, written as bf16
+ * (row pitch ld_bf16) and/or fp32; at least one output.  d % 4 == 0. */
+int asl_layernorm_f32(const float* x, int rows, int d, const float* gamma, const float* beta,
+                      float eps, void* y_bf16, int ld_bf16, float* y_f32, asl_stream_t stream);
+
+/* y[r][:] = x[r][:] + add[r % period][:]  (the positional-encoding add), fp32 and/or bf16 out. */
+int asl_add_rows_f32(const float* x, int rows, int d, const float* add, int period, float* y_f32,
+                     void* y_bf16, int ld_bf16, asl_stream_t stream);
+
+/* fp32 [rows][k] -> bf16 [rows][ld], columns >= k zeroed (K padding of a GEMM operand). */
+int asl_cast_pad_bf16(const float* x, int rows, int k, void* y_bf16, int ld, asl_stream_t stream);
+
+/* Self-attention core of nn.MultiheadAttention (batch_first, no mask, dropout 0):
+ * out[b, q, h*64:(h+1)*64] = softmax(Q_h K_h^T / sqrt(64)) V_h with Q|K|V the three heads*64-wide
+ * column blocks of qkv bf16 [batch*t][ld_qkv].  t <= 128, head_dim == 64.  out bf16 [batch*t][ld_out]. */
+typedef struct asl_attn_params {
+    int32_t batch, t, heads, head_dim;
+    int32_t ld_qkv, ld_out;
+} asl_attn_params;
+
+int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -297,8 +297,11 @@ def init_params(model, seed):
     g = torch.Generator().manual_seed(seed)
     for m in model.modules():
         if isinstance(m, (nn.Conv2d, nn.Conv3d)):
-            fan_out = m.weight.shape[0] * m.weight[0, 0].numel()
-            m.weight.normal_(0.0, math.sqrt(2.0 / fan_out), generator=g)
+            # He-normal: fan_out for the ResNets (torchvision's choice); fan_in for the Inception-style 3-D
+            # net, whose 1x1x1 bottlenecks change the channel count by up to 12x per layer -- fan_out there
+            # multiplies the forward variance by cin/cout each time (random-init logits of std ~1e3)
+            fan = m.weight[0].numel() if isinstance(m, nn.Conv3d) else m.weight.shape[0] * m.weight[0, 0].numel()
+            m.weight.normal_(0.0, math.sqrt(2.0 / fan), generator=g)
             if m.bias is not None:
                 m.bias.normal_(0.0, 0.1, generator=g)
         elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
@@ -306,6 +309,16 @@ def init_params(model, seed):
             m.bias.normal_(0.0, 0.1, generator=g)
             m.running_mean.normal_(0.0, 0.1, generator=g)
             m.running_var.uniform_(0.5, 1.5, generator=g)
+    # Last BatchNorm of every residual block: gamma ~ U(0.2, 0.6).  With gamma ~ 1 there, each of the 8
+    # (ResNet-18) or 16 (ResNet-50) blocks doubles the activation variance and a random-init ResNet-50
+    # ends with feature std ~ 340, which drives the LSTM gates so hard that any rounding is amplified
+    # ten-fold; a trained network (and torchvision's zero_init_residual) keeps the trunk O(1), and so
+    # does this.
+    for m in model.modules():
+        if isinstance(m, BasicBlock):
+            m.bn2.weight.uniform_(0.2, 0.6, generator=g)
+        elif isinstance(m, Bottleneck):
+            m.bn3.weight.uniform_(0.2, 0.6, generator=g)
     # Linear / LSTM / MultiheadAttention / LayerNorm: PyTorch's default scale, drawn from g
     for n, p in model.named_parameters():
         mod = n.rsplit(".", 1)[0]

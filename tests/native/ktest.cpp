@@ -232,7 +232,7 @@ static void check_linear(int m, int n, int k, bool f32out, bool relu, bool withr
     DBuf<float> dbi(n);
     DBuf<char> dy((size_t)m * n * 4);
     dx.up(x); dw.up(w); dbi.up(bi); dres.up(res);
-    asl_linear_params p = {m, n, k, k, n, n, relu, f32out, (n + 127) / 128 * 128};
+    asl_linear_params p = {m, n, k, k, n, n, relu, f32out, 0, (n + 127) / 128 * 128};
     int rc = asl_linear_bf16(&p, dx.p, dw.p, nullptr, dbi.p, withres ? dres.p : nullptr, dy.p, nullptr);
     char name[96];
     snprintf(name, sizeof name, "linear m%d n%d k%d %s%s%s", m, n, k, f32out ? "f32" : "bf16", relu ? " relu" : "", withres ? " +res" : "");
@@ -303,7 +303,7 @@ static void check_pools() {
         DBuf<uint16_t> df(f.size()), dfb((size_t)fr * cc);
         DBuf<float> dff((size_t)fr * cc), dmean((size_t)2 * cc);
         df.up(f);
-        rc = asl_avgpool_nhwc(df.p, fr, fh, fw, cc, halo, dff.p, dfb.p, cc, nullptr);
+        rc = asl_avgpool_nhwc(df.p, fr, fh, fw, cc, halo, dff.p, dfb.p, cc, 0, nullptr);
         if (!rc) rc = asl_mean_t_f32(dff.p, 2, 3, cc, dmean.p, nullptr);
         if (rc) { printf("avgpool/mean rc=%d FAIL\n", rc); ++g_fail; return; }
         HIP_CHECK(hipDeviceSynchronize());

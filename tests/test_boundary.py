@@ -38,9 +38,10 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(L.Conv2dParams) == 18 * 4
     assert C.sizeof(L.StemParams) == 12 * 4
     assert C.sizeof(L.Conv3dParams) == 21 * 4
-    assert C.sizeof(L.LinearParams) == 9 * 4
+    assert C.sizeof(L.LinearParams) == 10 * 4
+    assert C.sizeof(L.LstmParams) == 7 * 4 and C.sizeof(L.AttnParams) == 6 * 4
     assert C.sizeof(L.Pool3dParams) == 18 * 4
-    assert C.sizeof(L.GemmParams) == 12 * 4 + 3 * 24 + 3 * 4 + 4 + 3 * 8   # incl. 4 bytes of padding
+    assert C.sizeof(L.GemmParams) == 12 * 4 + 3 * 24 + 4 * 4 + 3 * 8
 
 
 def test_bad_geometry_is_rejected_without_launch():
@@ -58,13 +59,13 @@ def test_bad_geometry_is_rejected_without_launch():
     p.w_rows = 128
     assert L.lib.asl_conv2d_nhwc_bf16(C.byref(p), None, fake, None, None, None, fake, None) == L.ASL_EINVAL  # null x
     assert L.lib.asl_conv2d_nhwc_bf16(C.byref(p), C.c_void_p(0x1004), fake, None, None, None, fake, None) == L.ASL_EINVAL
-    lp = L.LinearParams(m=4, n=10, k=40, ldx=40, ldy=10, ldres=0, relu=0, out_f32=1, w_rows=128)
+    lp = L.LinearParams(m=4, n=10, k=40, ldx=40, ldy=10, ldres=0, relu=0, out_f32=1, res_f32=0, w_rows=128)
     assert L.lib.asl_linear_bf16(C.byref(lp), fake, fake, None, None, None, fake, None) == L.ASL_EINVAL      # k % 32
     sp = L.StemParams(n=1, h=32, w=32, in_halo=2, cout=64, kh=7, kw=7, stride=2, pad=3, out_halo=1, relu=1, w_rows=128)
     assert L.lib.asl_stem_conv_bf16(C.byref(sp), fake, fake, None, None, fake, None) == L.ASL_EINVAL          # halo < pad
     assert L.lib.asl_pack_clips(fake, 1, 1, 31, 3, fake, None) == L.ASL_EINVAL                                # odd size
     assert L.lib.asl_softmax_topk(fake, 1, 10, 17, fake, fake, None) == L.ASL_EINVAL                          # k > 16
-    assert L.lib.asl_avgpool_nhwc(fake, 1, 7, 7, 24 * 8, 1, fake, None, 0, None) == L.ASL_EINVAL              # c/8 not pow2
+    assert L.lib.asl_avgpool_nhwc(fake, 1, 7, 7, 24 * 8, 1, fake, None, 0, 0, None) == L.ASL_EINVAL              # c/8 not pow2
     with pytest.raises(RuntimeError, match="invalid argument"):
         L.check(L.ASL_EINVAL, "probe")
 

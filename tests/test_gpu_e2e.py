@@ -121,3 +121,26 @@ def test_full_size_linearity_property(gpu):
     # permuting the frames of a clip must not change a mean-pooled clip's logits beyond fp32 order effects
     perm = torch.randperm(64)
     torch.testing.assert_close(m(clips[:, perm]), y, rtol=1e-4, atol=1e-4)
+
+
+def test_resnet50_bilstm_matches_oracle(gpu):
+    om, m = _model("resnet50_bilstm", frames_per_chunk=16)
+    g = np.load(os.path.join(GOLDEN, "resnet50_bilstm_fwd_b2t8s224.npz"))
+    clips = O.make_clips(2, 8, 224, 0)
+    y = m(clips.cuda()).cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert rel_l2(y, ref) <= REL_TOL, rel_l2(y, ref)
+    assert torch.equal(y.argmax(1), ref.argmax(1))
+
+
+def test_twostream_transformer_matches_oracle(gpu):
+    om, m = _model("twostream_transformer", frames_per_chunk=32)
+    g = np.load(os.path.join(GOLDEN, "twostream_transformer_fwd_b2t16s224.npz"))
+    clips, kp = O.make_clips(2, 16, 224, 0), O.make_keypoints(2, 16, 0)
+    y = m(clips.cuda(), kp.cuda()).cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert y.shape == (2, 2000)
+    assert rel_l2(y, ref) <= REL_TOL, rel_l2(y, ref)
+    assert torch.equal(y.argmax(1), ref.argmax(1))
+    with pytest.raises(ValueError):
+        m(clips.cuda())

@@ -23,7 +23,7 @@ class GemmParams(C.Structure):
                 ("cout", C.c_int32), ("kd", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("ck", C.c_int32), ("tap_sd", C.c_int32), ("tap_sh", C.c_int32), ("tap_sw", C.c_int32),
                 ("in_", Geom), ("out", Geom), ("res", Geom),
-                ("relu", C.c_int32), ("out_f32", C.c_int32), ("w_rows", C.c_int32),
+                ("relu", C.c_int32), ("out_f32", C.c_int32), ("res_f32", C.c_int32), ("w_rows", C.c_int32),
                 ("x_elems", C.c_int64), ("y_elems", C.c_int64), ("res_elems", C.c_int64)]
 
 
@@ -45,13 +45,21 @@ class Conv3dParams(C.Structure):
 
 
 class LinearParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("m", "n", "k", "ldx", "ldy", "ldres", "relu", "out_f32", "w_rows")]
+    _fields_ = [(n, C.c_int32) for n in ("m", "n", "k", "ldx", "ldy", "ldres", "relu", "out_f32", "res_f32", "w_rows")]
 
 
 class Pool3dParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "d", "h", "w", "c", "in_halo_d", "in_halo", "kd", "kh", "kw", "sd", "sh", "sw",
         "pd", "ph", "pw", "out_halo_d", "out_halo")]
+
+
+class LstmParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("batch", "t", "hidden", "ld_gx", "ld_y", "split_y")] + [("ysum_scale", C.c_float)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("batch", "t", "heads", "head_dim", "ld_qkv", "ld_out")]
 
 
 if not os.path.exists(LIB_PATH):
@@ -75,10 +83,15 @@ _PROTOS = {
     "asl_preprocess_u8": ([_P, _I, _I, _I, _I, _I, _F3, _F3, _P, _P, _P], C.c_int),
     "asl_maxpool3x3s2_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _I, _P], C.c_int),
     "asl_maxpool3d_ndhwc": ([C.POINTER(Pool3dParams), _P, _P, _P], C.c_int),
-    "asl_avgpool_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _P, _I, _P], C.c_int),
+    "asl_avgpool_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P], C.c_int),
     "asl_mean_t_f32": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "asl_head_f32": ([_P, _I, _I, _P, _P, _I, _P, _P], C.c_int),
     "asl_softmax_topk": ([_P, _I, _I, _I, _P, _P, _P], C.c_int),
+    "asl_lstm_bidir_layer": ([C.POINTER(LstmParams), _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_layernorm_f32": ([_P, _I, _I, _P, _P, C.c_float, _P, _I, _P, _P], C.c_int),
+    "asl_add_rows_f32": ([_P, _I, _I, _P, _I, _P, _P, _I, _P], C.c_int),
+    "asl_cast_pad_bf16": ([_P, _I, _I, _P, _I, _P], C.c_int),
+    "asl_attention_fwd": ([C.POINTER(AttnParams), _P, _P, _P], C.c_int),
 }
 
 EXPORTS = tuple(_PROTOS)

@@ -124,7 +124,7 @@ extern "C" int asl_linear_bf16(const asl_linear_params* p, const void* x, const 
     g.nb = p->m; g.od = g.oh = g.ow = 1; g.cout = p->n;
     g.kd = g.kh = g.kw = 1; g.ck = p->k;
     g.in.sn = p->ldx; g.out.sn = p->ldy; g.res.sn = p->ldres;
-    g.relu = p->relu; g.out_f32 = p->out_f32; g.w_rows = p->w_rows;
+    g.relu = p->relu; g.out_f32 = p->out_f32; g.res_f32 = p->res_f32; g.w_rows = p->w_rows;
     g.x_elems = (int64_t)(p->m - 1) * p->ldx + p->k;
     g.y_elems = (int64_t)(p->m - 1) * p->ldy + p->n;
     g.res_elems = (int64_t)(p->m - 1) * p->ldres + p->n;

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const PatchArgs a) {
     g.OW = a.OW; g.OHW = a.OHW; g.ODHW = a.ODHW;
     g.out_sn = a.out_sn; g.out_sd = 0; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
     g.res_sn = a.res_sn; g.res_sd = 0; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
-    g.relu = a.relu; g.out_f32 = 0;
+    g.relu = a.relu; g.out_f32 = 0; g.res_f32 = 0;
     static_assert(NW * kEpiWaveBytes(FN * 16) <= kPatchBytes, "epilogue stage does not fit the patch buffer");
     epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(FN * 16), g, m0 + wave * 64, tn * BN, lane);
 #endif

@@ -20,6 +20,7 @@ struct OutGeom {
     int out_sd, out_sh, out_sw, out_off0;
     int res_sd, res_sh, res_sw, res_off0;
     int relu, out_f32;
+    int res_f32;                       // residual is fp32 instead of bf16 (same geometry)
 };
 
 constexpr int kEpiRowBytes(int wtn) { return wtn * 4 + 16; }          // fp32 row + 16 B pad
@@ -67,7 +68,7 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char*
             if (g.res) {
                 re[i][ps] = (long long)n * g.res_sn + (long long)d * g.res_sd + (long long)h * g.res_sh +
                             (long long)w_ * g.res_sw + g.res_off0 + ch;
-                if (ok[i][ps] && full) r8[i][ps] = *(const bf16x8*)(g.res + 2 * re[i][ps]);
+                if (ok[i][ps] && full && !g.res_f32) r8[i][ps] = *(const bf16x8*)(g.res + 2 * re[i][ps]);
             }
         }
 #pragma unroll
@@ -89,6 +90,10 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char*
                     v0[e] += bf16_to_f32(r8[i][ps][e]);
                     v1[e] += bf16_to_f32(r8[i][ps][4 + e]);
                 }
+                if (g.res && g.res_f32) {          // fp32 residual stream (small GEMMs only): loaded in place
+                    v0 += *(const f32x4*)(g.res + 4 * re[i][ps]);
+                    v1 += *(const f32x4*)(g.res + 4 * re[i][ps] + 16);
+                }
                 if (g.relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
@@ -107,7 +112,8 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char*
                     float t = e < 4 ? v0[e & 3] : v1[e & 3];
                     if (g.scale) t *= g.scale[ch + e];
                     if (g.bias) t += g.bias[ch + e];
-                    if (g.res) t += bf16_to_f32(*(const short*)(g.res + 2 * (re[i][ps] + e)));
+                    if (g.res) t += g.res_f32 ? *(const float*)(g.res + 4 * (re[i][ps] + e))
+                                              : bf16_to_f32(*(const short*)(g.res + 2 * (re[i][ps] + e)));
                     if (g.relu) t = fmaxf(t, 0.f);
                     if (g.out_f32) *(float*)(g.y + 4 * (o + e)) = t;
                     else *(short*)(g.y + 2 * (o + e)) = f32_to_bf16(t);

@@ -37,7 +37,7 @@ struct GemmArgs {
     int tap_sd, tap_sh, tap_sw;
     int wk;                      // packed K (elements per weight row)
     long long x_bytes, w_bytes;
-    int relu, out_f32;
+    int relu, out_f32, res_f32;
     int tiles_m, tiles_n;
 };
 
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
     g.OW = a.OW; g.OHW = a.OHW; g.ODHW = a.ODHW;
     g.out_sn = a.out_sn; g.out_sd = a.out_sd; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
     g.res_sn = a.res_sn; g.res_sd = a.res_sd; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
-    g.relu = a.relu; g.out_f32 = a.out_f32;
+    g.relu = a.relu; g.out_f32 = a.out_f32; g.res_f32 = a.res_f32;
     static_assert(NW * kEpiWaveBytes(WTN) <= 2 * BUF, "epilogue stage does not fit the K-loop LDS");
     epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(WTN), g, m0 + wm * WTM, tn * BN + wn * WTN, lane);
 #endif
@@ -288,12 +288,12 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
     a.tap_sd = p->tap_sd; a.tap_sh = p->tap_sh; a.tap_sw = p->tap_sw;
     a.wk = (int)wk;
     a.x_bytes = 2 * p->x_elems; a.w_bytes = 2 * wk * p->w_rows;
-    a.relu = p->relu; a.out_f32 = p->out_f32;
+    a.relu = p->relu; a.out_f32 = p->out_f32; a.res_f32 = p->res_f32;
     a.tiles_m = a.tiles_n = 0;
 
     hipStream_t s = (hipStream_t)stream;
     // 3x3 / stride 1 / pad 1 on a halo'd NHWC tensor with C % 64 == 0: the LDS-resident-patch kernel
-    if (p->kd == 1 && p->kh == 3 && p->kw == 3 && p->od == 1 && (p->ck & 63) == 0 && !p->out_f32 &&
+    if (p->kd == 1 && p->kh == 3 && p->kw == 3 && p->od == 1 && (p->ck & 63) == 0 && !p->out_f32 && !p->res_f32 &&
         p->tap_sw == p->ck && p->in.sw == p->ck && p->in.sh == p->tap_sh && p->tap_sh % p->ck == 0 &&
         p->in.sn % p->tap_sh == 0 && !getenv("ASL_NO_PATCH_CONV")) {
         const int C = p->ck, Wp = p->tap_sh / C, Hp = (int)(p->in.sn / p->tap_sh);

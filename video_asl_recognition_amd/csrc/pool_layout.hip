@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
 // block = one frame; lane layout (pixel slice, 8-channel chunk)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void avgpool_kernel(const short* __restrict__ x, int h, int w, int c, int halo,
-                                                      float* __restrict__ yf, short* __restrict__ yb, int ldb) {
+                                                      float* __restrict__ yf, short* __restrict__ yb, int ldb,
+                                                      int lo_off) {
     __shared__ float red[256 * 8];
     const int c8 = c >> 3;
     const int n = blockIdx.x;
@@ -173,7 +174,11 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const short* __restrict__ 
             for (int e = 0; e < 8; ++e) {
                 const float v = acc[e] * inv;
                 yf[(long long)n * c + 8 * (cb + ch) + e] = v;
-                if (yb) yb[(long long)n * ldb + 8 * (cb + ch) + e] = f32_to_bf16(v);
+                if (yb) {
+                    const short hi = f32_to_bf16(v);
+                    yb[(long long)n * ldb + 8 * (cb + ch) + e] = hi;
+                    if (lo_off > 0) yb[(long long)n * ldb + lo_off + 8 * (cb + ch) + e] = f32_to_bf16(v - bf16_to_f32(hi));
+                }
             }
         }
         __syncthreads();
@@ -331,15 +336,15 @@ extern "C" int asl_maxpool3x3s2_nhwc(const void* x, int n, int h, int w, int c, 
 }
 
 extern "C" int asl_avgpool_nhwc(const void* x, int n, int h, int w, int c, int halo, float* y_f32, void* y_bf16,
-                                int ld_bf16, asl_stream_t stream) {
+                                int ld_bf16, int lo_off, asl_stream_t stream) {
     if (!x || !y_f32 || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 7) || halo < 0) return ASL_EINVAL;
     const int c8 = c / 8;
     if (c8 < 256 && (c8 & (c8 - 1))) return ASL_EINVAL;       // lane layout needs 256 % chunks == 0
     if (c8 > 256 && (c8 % 256)) return ASL_EINVAL;
-    if (y_bf16 && ld_bf16 < c) return ASL_EINVAL;
+    if (y_bf16 && (ld_bf16 < c || lo_off < 0 || (lo_off > 0 && (lo_off < c || lo_off + c > ld_bf16)))) return ASL_EINVAL;
     if ((uintptr_t)x & 15) return ASL_EINVAL;
     hipLaunchKernelGGL(avgpool_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const short*)x, h, w, c, halo,
-                       y_f32, (short*)y_bf16, ld_bf16);
+                       y_f32, (short*)y_bf16, ld_bf16, lo_off);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,374 @@
+// Temporal-encoder kernels for gfx950: fused BiLSTM recurrence, LayerNorm, fused softmax
+// attention (MFMA QK^T / PV, shuffle reductions), and the small row-wise helpers around them.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "asl_hip.h"
+#include "common.h"
+
+namespace asl_detail {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float tanhf_(float v) {
+    // tanh(v) = 1 - 2 / (exp(2v) + 1); exact limits at +-inf, no cancellation near 0 beyond fp32 ulp
+    const float e = __expf(2.0f * v);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One time step of one bidirectional LSTM layer, both directions.  Thread = (direction, hidden
+// unit j, batch row b): four 512-long fp32 dot products h_prev[b] . W_hh[gate*H + j] (weights
+// bf16, read 8 at a time; neighbouring lanes share the weight rows), then the fused gate math
+// and state update.  h is kept in fp32 for the recurrence; the bf16 copy written to y feeds the
+// next layer's input GEMM.
+// ---------------------------------------------------------------------------------------------
+struct LstmArgs {
+    const float* gx;       // [B*T][ld_gx] fp32: x W_ih^T + b_ih + b_hh, forward gates then reverse gates
+    const short* whh;      // [2][4H][H] bf16
+    const float* h_prev;   // [2][B][H]
+    float* h_next;         // [2][B][H]
+    float* c;              // [2][B][H]
+    short* y;              // [B*T][ld_y] bf16: forward h at column 0, reverse h at column H
+    float* ysum;           // [B][2H] fp32 running sum over t (mean-pool numerator), or null
+    int B, T, H, ld_gx, ld_y, step, split_y;
+    float ysum_scale;
+};
+
+__global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a) {
+    const int per_dir = a.H * a.B;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 2 * per_dir) return;
+    const int d = idx / per_dir, rem = idx - d * per_dir;
+    const int j = rem / a.B, b = rem - j * a.B;
+    const int t = d == 0 ? a.step : a.T - 1 - a.step;
+    const int H = a.H;
+    const float* hp = a.h_prev + ((long long)d * a.B + b) * H;
+    const short* w = a.whh + (long long)d * 4 * H * H + (long long)j * H;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < H; k += 8) {
+        const f32x4 h0 = *(const f32x4*)(hp + k), h1 = *(const f32x4*)(hp + k + 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bf16x8 wv = *(const bf16x8*)(w + (long long)g * H * H + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[g] = fmaf(h0[e], bf16_to_f32(wv[e]), acc[g]);
+                acc[g] = fmaf(h1[e], bf16_to_f32(wv[4 + e]), acc[g]);
+            }
+        }
+    }
+    const float* gx = a.gx + ((long long)b * a.T + t) * a.ld_gx + d * 4 * H + j;
+    const float gi = sigmoidf_(acc[0] + gx[0]);
+    const float gf = sigmoidf_(acc[1] + gx[H]);
+    const float gg = tanhf_(acc[2] + gx[2 * H]);
+    const float go = sigmoidf_(acc[3] + gx[3 * H]);
+    const long long si = ((long long)d * a.B + b) * H + j;
+    const float cn = gf * a.c[si] + gi * gg;
+    const float hn = go * tanhf_(cn);
+    a.c[si] = cn;
+    a.h_next[si] = hn;
+    short* yr = a.y + ((long long)b * a.T + t) * a.ld_y + d * H + j;
+    const short hi = f32_to_bf16(hn);
+    yr[0] = hi;
+    if (a.split_y) yr[2 * H] = f32_to_bf16(hn - bf16_to_f32(hi));
+    if (a.ysum) a.ysum[(long long)b * 2 * H + d * H + j] += hn * a.ysum_scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension, one wave per row, fp32 in, bf16 and/or fp32 out.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int rows, int d,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        short* __restrict__ yb, int ldb, float* __restrict__ yf) {
+    const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (long long)row * d;
+    float s = 0.f;
+    for (int k = lane * 4; k < d; k += 256) {
+        const f32x4 v = *(const f32x4*)(xr + k);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int k = lane * 4; k < d; k += 256) {
+        const f32x4 v = *(const f32x4*)(xr + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q += (v[e] - mean) * (v[e] - mean);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    for (int k = lane * 4; k < d; k += 256) {
+        const f32x4 v = *(const f32x4*)(xr + k);
+        const f32x4 g = *(const f32x4*)(gamma + k), b = *(const f32x4*)(beta + k);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * g[e] + b[e];
+        if (yf) *(f32x4*)(yf + (long long)row * d + k) = o;
+        if (yb) {
+            bf16x4 ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = f32_to_bf16(o[e]);
+            *(bf16x4*)(yb + (long long)row * ldb + k) = ob;
+        }
+    }
+}
+
+// y = x + add[row % period]  (fp32), optional bf16 copy: the positional-encoding add
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ x, int rows, int d,
+                                                       const float* __restrict__ add, int period,
+                                                       float* __restrict__ yf, short* __restrict__ yb, int ldb) {
+    const long long total = (long long)rows * (d / 4);
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i / (d / 4);
+        const int k = (int)(i - row * (d / 4)) * 4;
+        f32x4 v = *(const f32x4*)(x + row * d + k);
+        const f32x4 p = *(const f32x4*)(add + (row % period) * d + k);
+        v += p;
+        if (yf) *(f32x4*)(yf + row * d + k) = v;
+        if (yb) {
+            bf16x4 ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = f32_to_bf16(v[e]);
+            *(bf16x4*)(yb + row * ldb + k) = ob;
+        }
+    }
+}
+
+// fp32 [rows][k] -> bf16 [rows][ld] with columns >= k zeroed (GEMM K padding)
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ x, int rows, int k, short* __restrict__ y,
+                                                       int ld) {
+    const long long total = (long long)rows * ld;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i / ld;
+        const int c = (int)(i - row * ld);
+        y[i] = c < k ? f32_to_bf16(x[row * k + c]) : (short)0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused softmax attention for short sequences (T <= 128, head_dim 64): one workgroup of 4 waves per
+// (batch, head); wave w owns query rows [32w, 32w+32).  S = Q K^T by MFMA with keys on the
+// accumulator rows, so a lane holds 4 consecutive keys of one query per tile and the softmax
+// row reductions are two lane shuffles (xor 16, xor 32) plus in-register work.  P goes through LDS
+// (bf16) to become the A operand of O = P V; V is staged transposed so its fragments are 16-byte
+// reads as well.
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const short* qkv;   // [B*T][ld_qkv] bf16: q | k | v, each heads*64 wide
+    short* out;         // [B*T][ld_out] bf16
+    int B, T, heads, ld_qkv, ld_out;
+    float scale;
+};
+
+constexpr int kAttnT = 128, kAttnD = 64;
+
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // LDS: K [128][64] (swizzled 16-B chunks), V^T [64][128+8], P [4 waves][32][128+8]
+    __shared__ __attribute__((aligned(16))) short k_lds[kAttnT * kAttnD];
+    __shared__ __attribute__((aligned(16))) short vt_lds[kAttnD * (kAttnT + 8)];
+    __shared__ __attribute__((aligned(16))) short p_lds[4 * 32 * (kAttnT + 8)];
+    constexpr int VTP = kAttnT + 8, PP = kAttnT + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int D = a.heads * kAttnD;
+    const short* qb = a.qkv + (long long)b * a.T * a.ld_qkv + h * kAttnD;
+    const short* kb = qb + D;
+    const short* vb = qb + 2 * D;
+    const int T = a.T;
+
+    // stage K (row-major, chunk-swizzled) and V^T; rows >= T are zero
+    for (int i = tid; i < kAttnT * 8; i += 256) {
+        const int row = i >> 3, ch = i & 7;
+        bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+        if (row < T) {
+            kv = *(const bf16x8*)(kb + (long long)row * a.ld_qkv + ch * 8);
+            vv = *(const bf16x8*)(vb + (long long)row * a.ld_qkv + ch * 8);
+        }
+        *(bf16x8*)(k_lds + row * kAttnD + ((ch ^ ((row >> 1) & 7)) << 3)) = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vt_lds[(ch * 8 + e) * VTP + row] = vv[e];
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // Q fragments straight from global: B operand (columns = queries): lane -> query fr, k chunk fq
+    bf16x8 qf[2][2];                            // [query tile][k step]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = wave * 32 + qt * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[qt][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (q < T) qf[qt][ks] = *(const bf16x8*)(qb + (long long)q * a.ld_qkv + (ks * 4 + fq) * 8);
+        }
+    }
+    // S^T tiles: rows = keys (8 tiles of 16), columns = queries (2 tiles of 16)
+    f32x4 s[8][2];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+        const int row = kt * 16 + fr;
+        bf16x8 kf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            kf[ks] = *(const bf16x8*)(k_lds + row * kAttnD + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 3));
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[qt][ks], acc, 0, 0, 0);
+            s[kt][qt] = acc;
+        }
+    }
+    // lane holds, for query (qt, fr), keys kt*16 + fq*4 + e.  Softmax over keys:
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = kt * 16 + fq * 4 + e;
+                const float v = key < T ? s[kt][qt][e] * a.scale : -INFINITY;
+                s[kt][qt][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = __expf(s[kt][qt][e] - mx);
+                s[kt][qt][e] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        // P[q][key] (bf16) into this wave's LDS slab: 4 consecutive keys per store
+        short* prow = p_lds + (wave * 32 + qt * 16 + fr) * PP;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            bf16x4 pv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv[e] = f32_to_bf16(s[kt][qt][e] * inv);
+            *(bf16x4*)(prow + kt * 16 + fq * 4) = pv;
+        }
+    }
+    // O^T = V^T P^T: A operand = V^T rows (head dims), B operand = P rows (queries); k = keys
+    f32x4 o[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {             // 4 steps of 32 keys
+        bf16x8 pf[2], vf[4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+            pf[qt] = *(const bf16x8*)(p_lds + (wave * 32 + qt * 16 + fr) * PP + ks * 32 + fq * 8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vf[dt] = *(const bf16x8*)(vt_lds + (dt * 16 + fr) * VTP + ks * 32 + fq * 8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+                o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt], pf[qt], o[dt][qt], 0, 0, 0);
+    }
+    // lane holds head dims dt*16 + fq*4 + e of query (qt, fr): 8-byte stores
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = wave * 32 + qt * 16 + fr;
+        if (q >= T) continue;
+        short* orow = a.out + ((long long)b * T + q) * a.ld_out + h * kAttnD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = f32_to_bf16(o[dt][qt][e]);
+            *(bf16x4*)(orow + dt * 16 + fq * 4) = ov;
+        }
+    }
+#endif
+}
+
+int grid_rows(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace asl_detail
+using namespace asl_detail;
+
+extern "C" int asl_lstm_bidir_layer(const asl_lstm_params* p, const float* gx, const void* w_hh, void* y_bf16,
+                                    float* ysum, float* state, asl_stream_t stream) {
+    if (!p || !gx || !w_hh || !y_bf16 || !state) return ASL_EINVAL;
+    if (p->batch <= 0 || p->t <= 0 || p->hidden <= 0 || (p->hidden & 7)) return ASL_EINVAL;
+    if (p->ld_gx < 8 * p->hidden || p->ld_y < (p->split_y ? 4 : 2) * p->hidden) return ASL_EINVAL;
+    if (((uintptr_t)w_hh & 15) || ((uintptr_t)state & 15)) return ASL_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = 2LL * p->batch * p->hidden;           // elements of one [2][B][H] state array
+    // state = h ping | h pong | c ; zero initial state, and the running sum if requested
+    hipError_t e = hipMemsetAsync(state, 0, (size_t)(3 * n) * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    if (ysum) {
+        e = hipMemsetAsync(ysum, 0, (size_t)n * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    LstmArgs a;
+    a.gx = gx; a.whh = (const short*)w_hh; a.c = state + 2 * n; a.y = (short*)y_bf16; a.ysum = ysum;
+    a.B = p->batch; a.T = p->t; a.H = p->hidden; a.ld_gx = p->ld_gx; a.ld_y = p->ld_y;
+    a.ysum_scale = p->ysum_scale; a.split_y = p->split_y;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    for (int step = 0; step < p->t; ++step) {
+        a.h_prev = state + (step & 1) * n;
+        a.h_next = state + ((step + 1) & 1) * n;
+        a.step = step;
+        hipLaunchKernelGGL(lstm_step_kernel, dim3(blocks), dim3(256), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_layernorm_f32(const float* x, int rows, int d, const float* gamma, const float* beta, float eps,
+                                 void* y_bf16, int ld_bf16, float* y_f32, asl_stream_t stream) {
+    if (!x || !gamma || !beta || rows <= 0 || d <= 0 || (d & 3) || (!y_bf16 && !y_f32)) return ASL_EINVAL;
+    if (y_bf16 && (ld_bf16 < d || (ld_bf16 & 3))) return ASL_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)y_f32 & 15) ||
+        ((uintptr_t)y_bf16 & 7))
+        return ASL_EINVAL;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows, d,
+                       gamma, beta, eps, (short*)y_bf16, ld_bf16, y_f32);
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_add_rows_f32(const float* x, int rows, int d, const float* add, int period, float* y_f32,
+                                void* y_bf16, int ld_bf16, asl_stream_t stream) {
+    if (!x || !add || rows <= 0 || d <= 0 || (d & 3) || period <= 0 || (!y_bf16 && !y_f32)) return ASL_EINVAL;
+    if (y_bf16 && (ld_bf16 < d || (ld_bf16 & 3))) return ASL_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)add & 15) || ((uintptr_t)y_f32 & 15) || ((uintptr_t)y_bf16 & 7)) return ASL_EINVAL;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_rows((long long)rows * (d / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                       rows, d, add, period, y_f32, (short*)y_bf16, ld_bf16);
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_cast_pad_bf16(const float* x, int rows, int k, void* y_bf16, int ld, asl_stream_t stream) {
+    if (!x || !y_bf16 || rows <= 0 || k <= 0 || ld < k) return ASL_EINVAL;
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_rows((long long)rows * ld)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       k, (short*)y_bf16, ld);
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_stream_t stream) {
+    if (!p || !qkv || !out) return ASL_EINVAL;
+    if (p->batch <= 0 || p->heads <= 0 || p->t <= 0 || p->t > kAttnT || p->head_dim != kAttnD) return ASL_EINVAL;
+    if (p->ld_qkv < 3 * p->heads * kAttnD || (p->ld_qkv & 7) || p->ld_out < p->heads * kAttnD || (p->ld_out & 3))
+        return ASL_EINVAL;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return ASL_EINVAL;
+    AttnArgs a;
+    a.qkv = (const short*)qkv; a.out = (short*)out; a.B = p->batch; a.T = p->t; a.heads = p->heads;
+    a.ld_qkv = p->ld_qkv; a.ld_out = p->ld_out; a.scale = 1.0f / sqrtf((float)kAttnD);
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(p->batch * p->heads)), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}

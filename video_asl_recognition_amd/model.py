@@ -220,7 +220,14 @@ class AslClipModel:
         plan = self._get_plan(n_total)
         F = self.spec.feat_dim
         feats = torch.empty(n_total, F, dtype=torch.float32, device=self.device)
-        feats_b = torch.empty(n_total, F, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
+        # bf16 copy of the features = GEMM operand of the temporal encoder; the two-stream model appends
+        # the keypoint-MLP output to each row, so the row pitch may exceed F
+        # and the BiLSTM takes split-precision features (hi | lo halves) for its input projection
+        ld_b = F + (self.spec.kp_hidden if self.spec.temporal == "transformer" else 0)
+        lo_off = 0
+        if self.spec.temporal == "bilstm":
+            ld_b, lo_off = 2 * F, F
+        feats_b = torch.empty(n_total, ld_b, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         last: Act = plan["last"]
         step = plan["nmax"]
@@ -229,9 +236,9 @@ class AslClipModel:
             fill_x0(c0, n, plan["x0"], plan["in_halo"], stream)
             for op in plan["ops"]:
                 op(n, stream)
-            fb = None if feats_b is None else C.c_void_p(feats_b.data_ptr() + c0 * F * 2)
+            fb = None if feats_b is None else C.c_void_p(feats_b.data_ptr() + c0 * ld_b * 2)
             L.check(L.lib.asl_avgpool_nhwc(_ptr(last.t), n, last.h, last.w, last.c, last.halo,
-                                           C.c_void_p(feats.data_ptr() + c0 * F * 4), fb, F, stream), "avgpool")
+                                           C.c_void_p(feats.data_ptr() + c0 * F * 4), fb, ld_b, lo_off, stream), "avgpool")
         return feats, feats_b
 
     def frame_features(self, clips: torch.Tensor, want_bf16: bool = False):
@@ -268,7 +275,7 @@ class AslClipModel:
             L.check(L.lib.asl_head_f32(_ptr(pooled), B, F, _ptr(self._fc_w), _ptr(self._fc_b), spec.num_classes,
                                        _ptr(logits), stream), "head")
             return logits
-        return self._temporal(feats, feats_b, B, T, keypoints, stream)
+        return self._temporal(feats, feats_b, feats_b.shape[1], B, T, keypoints, stream)
 
     @torch.no_grad()
     def forward(self, clips: torch.Tensor, keypoints: Optional[torch.Tensor] = None) -> torch.Tensor:
