@@ -131,7 +131,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}, all-gather of logits"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "gather_gemm_kernel (all conv launches of one step)",
+                "kernel": "conv MFMA kernels (gather_gemm_kernel + conv3x3_patch_kernel), all conv launches of one step",
                 "achieved": round(achieved, 2),
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

@@ -188,6 +188,11 @@ int asl_avgpool_nhwc(const void* x, int n, int h, int w, int c, int halo,
 /* y[r][c] = mean over t of x[r][t][c]  (fp32 [rows][t][c] -> fp32 [rows][c]) */
 int asl_mean_t_f32(const float* x, int rows, int t, int c, float* y, asl_stream_t stream);
 
+/* The temporal half of F.avg_pool3d(x, (window,h,w), stride 1) followed by the mean over the remaining
+ * steps, on per-frame spatial means: y[r][c] = mean_{t'<=t-window} mean_{k<window} x[r][t'+k][c]. */
+int asl_window_mean_t_f32(const float* x, int rows, int t, int c, int window, float* y,
+                          asl_stream_t stream);
+
 /* nn.Linear(f, c) for a handful of rows, all fp32: y[m][c] = x[m][:] . w[c][:] + b[c]. */
 int asl_head_f32(const float* x, int m, int f, const float* w, const float* b, int c,
                  float* y, asl_stream_t stream);

@@ -49,3 +49,5 @@ if __name__ == "__main__":
     forward_case("resnet50_bilstm", 2, 8, 224, 0, heavy=1)
     forward_case("twostream_transformer", 2, 16, 224, 0, heavy=1)
     forward_case("i3d", 1, 16, 224, 0, heavy=1)
+    forward_case("i3d", 1, 32, 224, 0, heavy=1)
+    forward_case("i3d", 1, 64, 224, 0, heavy=1)

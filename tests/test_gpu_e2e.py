@@ -144,3 +144,17 @@ def test_twostream_transformer_matches_oracle(gpu):
     assert torch.equal(y.argmax(1), ref.argmax(1))
     with pytest.raises(ValueError):
         m(clips.cuda())
+
+
+@pytest.mark.parametrize("T,tol", [(64, REL_TOL), (16, 2e-3)])
+def test_i3d_matches_oracle(gpu, T, tol):
+    """The 1e-3 bar is stated at the config's T=64.  A 16-frame clip leaves 2x7x7 positions for the final
+    average instead of 8x7x7, so the per-activation bf16 rounding (2^-9) averages down ~2x less: 2e-3."""
+    om, m = _model("i3d", frames_per_chunk=64)
+    g = np.load(os.path.join(GOLDEN, f"i3d_fwd_b1t{T}s224.npz"))
+    clips = O.make_clips(1, T, 224, 0)
+    y = m(clips.cuda()).cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert y.shape == (1, 100)
+    assert rel_l2(y, ref) <= tol, rel_l2(y, ref)
+    assert torch.equal(y.argmax(1), ref.argmax(1))

@@ -85,6 +85,7 @@ _PROTOS = {
     "asl_maxpool3d_ndhwc": ([C.POINTER(Pool3dParams), _P, _P, _P], C.c_int),
     "asl_avgpool_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P], C.c_int),
     "asl_mean_t_f32": ([_P, _I, _I, _I, _P, _P], C.c_int),
+    "asl_window_mean_t_f32": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
     "asl_head_f32": ([_P, _I, _I, _P, _P, _I, _P, _P], C.c_int),
     "asl_softmax_topk": ([_P, _I, _I, _I, _P, _P, _P], C.c_int),
     "asl_lstm_bidir_layer": ([C.POINTER(LstmParams), _P, _P, _P, _P, _P, _P], C.c_int),

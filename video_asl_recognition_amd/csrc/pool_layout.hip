@@ -199,6 +199,27 @@ __global__ __launch_bounds__(256) void mean_t_kernel(const float* __restrict__ x
     }
 }
 
+// F.avg_pool3d's temporal part followed by the mean over the remaining steps:
+// y[r][c] = mean_{t'=0..t-window} mean_{k<window} x[r][t'+k][c]
+__global__ __launch_bounds__(256) void window_mean_t_kernel(const float* __restrict__ x, int rows, int t, int c,
+                                                            int window, float* __restrict__ y) {
+    const long long total = (long long)rows * c;
+    const int nout = t - window + 1;
+    const float iw = 1.0f / (float)window, io = 1.0f / (float)nout;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / c;
+        const int ch = (int)(i - r * c);
+        const float* p = x + r * t * c + ch;
+        float s = 0.f;
+        for (int o = 0; o < nout; ++o) {
+            float a = 0.f;
+            for (int k = 0; k < window; ++k) a += p[(long long)(o + k) * c];
+            s += a * iw;
+        }
+        y[i] = s * io;
+    }
+}
+
 // one wave per output element: dot product over f with a shuffle reduction
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, int m, int f,
                                                    const float* __restrict__ w, const float* __restrict__ b, int c,
@@ -352,6 +373,13 @@ extern "C" int asl_mean_t_f32(const float* x, int rows, int t, int c, float* y, 
     if (!x || !y || rows <= 0 || t <= 0 || c <= 0) return ASL_EINVAL;
     hipLaunchKernelGGL(mean_t_kernel, dim3(grid_for((long long)rows * c)), dim3(256), 0, (hipStream_t)stream, x, rows,
                        t, c, y);
+    return (int)hipGetLastError();
+}
+
+extern "C" int asl_window_mean_t_f32(const float* x, int rows, int t, int c, int window, float* y, asl_stream_t stream) {
+    if (!x || !y || rows <= 0 || t <= 0 || c <= 0 || window <= 0 || window > t) return ASL_EINVAL;
+    hipLaunchKernelGGL(window_mean_t_kernel, dim3(grid_for((long long)rows * c)), dim3(256), 0, (hipStream_t)stream, x,
+                       rows, t, c, window, y);
     return (int)hipGetLastError();
 }
 

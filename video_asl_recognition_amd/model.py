@@ -111,10 +111,17 @@ class AslClipModel:
                 if ds:
                     s, b = bn_scale_bias(sd, f"{prefix}.downsample.1", 1e-5, dev)
                     w[f"{prefix}.ds"] = pack_conv(sd[f"{prefix}.downsample.0.weight"], dev, scale=s, bias=b)
+        elif spec.backbone == "i3d":
+            from .i3d import pack_i3d_weights
+            w = pack_i3d_weights(spec, sd, dev)
+            self._fc_w = sd["backbone.logits.weight"].float().reshape(spec.num_classes, -1).contiguous().to(dev)
+            self._fc_b = sd["backbone.logits.bias"].float().contiguous().to(dev)
         else:
             raise NotImplementedError(f"backbone {spec.backbone}")
         self._w = w
-        if spec.temporal == "mean":
+        if spec.temporal == "i3d":
+            pass
+        elif spec.temporal == "mean":
             self._fc_w = sd["fc.weight"].float().contiguous().to(dev)
             self._fc_b = sd["fc.bias"].float().contiguous().to(dev)
         else:
@@ -277,11 +284,52 @@ class AslClipModel:
             return logits
         return self._temporal(feats, feats_b, feats_b.shape[1], B, T, keypoints, stream)
 
+    # ------------------------------------------------------------------ I3D
+    def _run_i3d(self, B: int, T: int, fill_frames):
+        """fill_frames(f0, n, dst_ptr, stream) writes frames [f0, f0+n) (flattened over B*T) as packed
+        [n][S+6][S+6][4] at dst_ptr.  Clips run through the 3-D backbone `clips_per_chunk` at a time."""
+        from .i3d import I3dPlan
+        spec, dev, S = self.spec, self.device, self.spec.size
+        per = max(1, self.frames_per_chunk // T)
+        nmax = min(B, per)
+        plan = self._plan
+        if not isinstance(plan, I3dPlan) or plan.T != T or plan.nmax < nmax:
+            plan = self._plan = I3dPlan(spec, self._w, nmax, T, dev)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        last = plan.last
+        D, Fdim = last.d, spec.feat_dim
+        frame_feats = torch.empty(B * D, last.c, dtype=torch.float32, device=dev)
+        plane = (S + 6) * (S + 6) * 4
+        for b0 in range(0, B, plan.nmax):
+            n = min(plan.nmax, B - b0)
+            for b in range(n):      # frames of clip b sit behind 3 zero halo frames of its own padded depth axis
+                dst = plan.x0.data_ptr() + ((b * (T + 6) + 3) * plane) * 2
+                fill_frames((b0 + b) * T, T, C.c_void_p(dst), stream)
+            for op in plan.ops:
+                op(n, stream)
+            L.check(L.lib.asl_avgpool_nhwc(_ptr(last.t), n * D, last.h, last.w, last.c, last.hh,
+                                           C.c_void_p(frame_feats.data_ptr() + b0 * D * last.c * 4), None, 0, 0, stream),
+                    "avgpool")
+        pooled = torch.empty(B, last.c, dtype=torch.float32, device=dev)
+        L.check(L.lib.asl_window_mean_t_f32(_ptr(frame_feats), B, D, last.c, min(2, D), _ptr(pooled), stream), "window_mean")
+        logits = torch.empty(B, spec.num_classes, dtype=torch.float32, device=dev)
+        L.check(L.lib.asl_head_f32(_ptr(pooled), B, last.c, _ptr(self._fc_w), _ptr(self._fc_b), spec.num_classes,
+                                   _ptr(logits), stream), "head")
+        return logits
+
     @torch.no_grad()
     def forward(self, clips: torch.Tensor, keypoints: Optional[torch.Tensor] = None) -> torch.Tensor:
         if not self._w:
             raise RuntimeError("load_state_dict() first (or construct with seed=...)")
         B, T = clips.shape[:2]
+        if self.spec.backbone == "i3d":
+            clips = self._check_clips(clips)
+            S, esz, in_f32, base = self.spec.size, clips.element_size(), int(clips.dtype == torch.float32), clips.data_ptr()
+
+            def fill(f0, n, dst, stream):
+                L.check(L.lib.asl_pack_clips(C.c_void_p(base + f0 * 3 * S * S * esz), in_f32, n, S, 3, dst, stream),
+                        "pack_clips")
+            return self._run_i3d(B, T, fill)
         if self.spec.keypoints and keypoints is None:
             raise ValueError(f"spec {self.spec.name} needs keypoints [B,T,21,2]")
         feats, feats_b = self.frame_features(clips, want_bf16=self.spec.temporal != "mean")
@@ -310,8 +358,14 @@ class AslClipModel:
         def fill(c0, n, x0, in_halo, stream):
             L.check(L.lib.asl_preprocess_u8(C.c_void_p(base + c0 * H0 * W0 * 3), n, H0, W0, S, in_halo, mean, std,
                                             _ptr(x0), None, stream), "preprocess")
-        feats, feats_b = self._run_backbone(B * T, fill, self.spec.temporal != "mean")
-        logits = self._head(feats, feats_b, B, T, keypoints)
+        if self.spec.backbone == "i3d":
+            def fill3(f0, n, dst, stream):
+                L.check(L.lib.asl_preprocess_u8(C.c_void_p(base + f0 * H0 * W0 * 3), n, H0, W0, S, 3, mean, std, dst,
+                                                None, stream), "preprocess")
+            logits = self._run_i3d(B, T, fill3)
+        else:
+            feats, feats_b = self._run_backbone(B * T, fill, self.spec.temporal != "mean")
+            logits = self._head(feats, feats_b, B, T, keypoints)
         k = int(topk)
         idx = torch.empty(B, k, dtype=torch.int64, device=self.device)
         prob = torch.empty(B, k, dtype=torch.float32, device=self.device)
@@ -336,7 +390,11 @@ class AslClipModel:
         return out
 
     def workspace_bytes(self) -> int:
-        return 0 if self._plan is None else self._plan["pool"].nbytes() + self._plan["x0"].numel() * 2
+        if self._plan is None:
+            return 0
+        if isinstance(self._plan, dict):
+            return self._plan["pool"].nbytes() + self._plan["x0"].numel() * 2
+        return self._plan.nbytes()
 
 
 def init_state_dict(spec: ModelSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
