@@ -120,6 +120,20 @@ typedef struct asl_stem_params {
 int asl_stem_conv_bf16(const asl_stem_params* p, const void* x, const void* w,
                        const float* scale, const float* bias, void* y, asl_stream_t stream);
 
+/* The ResNet stem fused with its pool: nn.Conv2d(3, 64, 7, stride 2, pad 3, bias=False) +
+ * BatchNorm2d(eval) + ReLU + nn.MaxPool2d(3, 2, 1) in one kernel (the 112x112x64 stem activation
+ * never reaches HBM).  x: packed [n][h+6][w+6][4] bf16 (asl_pack_clips / asl_preprocess_u8 with halo
+ * 3); w packed as for asl_stem_conv_bf16 ([w_rows][7*32]); y: [n][h/4+2*out_halo][w/4+2*out_halo][64].
+ * h, w multiples of 4; cout must be 64 (ASL_ENOTSUP otherwise). */
+typedef struct asl_stem_pool_params {
+    int32_t n, h, w;
+    int32_t cout, out_halo;
+    int32_t w_rows;
+} asl_stem_pool_params;
+
+int asl_stem_pool_bf16(const asl_stem_pool_params* p, const void* x, const void* w,
+                       const float* scale, const float* bias, void* y, asl_stream_t stream);
+
 /* nn.Conv3d(cin, cout, (kd,kh,kw), stride, pad=k//2, bias=False) + BatchNorm3d(eval) + ReLU
  * on halo'd NDHWC bf16: x [n][d+2*in_halo_d][h+2*in_halo][w+2*in_halo][cin]. */
 typedef struct asl_conv3d_params {

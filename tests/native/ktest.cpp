@@ -218,6 +218,32 @@ static void check_stem(int n, int s, int cout, int out_halo) {
     char name[96];
     snprintf(name, sizeof name, "stem7x7 n%d s%d ->%d ho%d", n, s, cout, out_halo);
     report(name, maxerr, 1e-2, bad);
+    if (cout != 64 || out_halo != 1) return;
+    // fused stem + maxpool must equal maxpool(the stem output just checked), bit for bit
+    const int ps = os / 2, psp = ps + 2;
+    DBuf<uint16_t> dp((size_t)n * psp * psp * 64), dq((size_t)n * psp * psp * 64);
+    HIP_CHECK(hipMemset(dp.p, 0x7f, dp.n * 2));
+    HIP_CHECK(hipMemset(dq.p, 0x7f, dq.n * 2));
+    // the unfused stem left poison in its halo; zero it the way the planner's torch.zeros would
+    std::vector<uint16_t> yz = y;
+    for (int i = 0; i < n; ++i)
+        for (int yy = 0; yy < osp; ++yy)
+            for (int xx = 0; xx < osp; ++xx)
+                if (yy == 0 || yy == osp - 1 || xx == 0 || xx == osp - 1)
+                    for (int o = 0; o < 64; ++o) yz[(((size_t)i * osp + yy) * osp + xx) * 64 + o] = 0;
+    dy.up(yz);
+    rc = asl_maxpool3x3s2_nhwc(dy.p, n, os, os, 64, 1, dp.p, 1, nullptr);
+    asl_stem_pool_params spp = {n, s, s, 64, 1, wrows};
+    if (!rc) rc = asl_stem_pool_bf16(&spp, dx.p, dw.p, dsc.p, dbi.p, dq.p, nullptr);
+    if (rc) { printf("stem_pool rc=%d (%s) FAIL\n", rc, asl_strerror(rc)); ++g_fail; return; }
+    HIP_CHECK(hipDeviceSynchronize());
+    auto pa = dp.down();
+    auto pb = dq.down();
+    bad = 0;
+    for (size_t i = 0; i < pa.size(); ++i)
+        if (pa[i] != pb[i]) ++bad;
+    snprintf(name, sizeof name, "fused stem+maxpool n%d s%d == maxpool(stem) (exact)", n, s);
+    report(name, 0, 0, bad);
 }
 
 static void check_linear(int m, int n, int k, bool f32out, bool relu, bool withres) {
@@ -420,6 +446,15 @@ static void bench(int frames) {
         const double bytes = (double)frames * (114.0 * 114 + 58.0 * 58) * 64 * 2;
         printf("%-28s %8.3f ms  %7.1f GB/s\n", "maxpool 3x3s2 @112", ms, bytes / ms * 1e-6);
         total_ms += ms;
+        asl_stem_pool_params sp = {frames, s, s, 64, 1, 128};
+        for (int it = 0; it < 2; ++it) asl_stem_pool_bf16(&sp, dx.p, dw.p, nullptr, nullptr, dp.p, nullptr);
+        HIP_CHECK(hipEventRecord(e0));
+        for (int it = 0; it < iters; ++it) asl_stem_pool_bf16(&sp, dx.p, dw.p, nullptr, nullptr, dp.p, nullptr);
+        HIP_CHECK(hipEventRecord(e1));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= iters;
+        printf("%-28s %8.3f ms  %7.1f TFLOP/s (algorithmic)  [replaces stem + maxpool]\n", "fused stem+maxpool", ms, flop / ms * 1e-9);
     }
     for (const auto& L : layers) {
         const int pad = L.k / 2, hp = L.hw + 2, o = (L.hw + 2 * pad - L.k) / L.stride + 1, op = o + 2;
@@ -481,6 +516,8 @@ int main(int argc, char** argv) {
         };
         for (const auto& c : cases) check_conv(c);
         check_stem(2, 32, 64, 1);
+        check_stem(3, 56, 64, 1);
+        check_stem(1, 224, 64, 1);
         check_stem(1, 48, 32, 0);
         check_linear(5, 100, 512, true, false, false);
         check_linear(130, 2048, 1024, false, true, true);

@@ -38,6 +38,10 @@ class StemParams(C.Structure):
         "n", "h", "w", "in_halo", "cout", "kh", "kw", "stride", "pad", "out_halo", "relu", "w_rows")]
 
 
+class StemPoolParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "cout", "out_halo", "w_rows")]
+
+
 class Conv3dParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "d", "h", "w", "cin", "in_halo_d", "in_halo", "cout", "kd", "kh", "kw", "stride_d", "stride",
@@ -77,6 +81,7 @@ _PROTOS = {
     "asl_gather_gemm_bf16": ([C.POINTER(GemmParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_conv2d_nhwc_bf16": ([C.POINTER(Conv2dParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_stem_conv_bf16": ([C.POINTER(StemParams), _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_stem_pool_bf16": ([C.POINTER(StemPoolParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_conv3d_ndhwc_bf16": ([C.POINTER(Conv3dParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_linear_bf16": ([C.POINTER(LinearParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_pack_clips": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),

@@ -14,6 +14,7 @@ once and reused) stay a fixed size whatever B*T is.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -172,15 +173,25 @@ class AslClipModel:
         else:
             in_halo = 3
             x0 = torch.zeros(nmax, S + 6, S + 6, 4, dtype=torch.bfloat16, device=dev)
-            a = pool.get(S // 2, S // 2, 64)
-            stem_op(self._w["stem"], x0, in_halo, a, 2, 3, True)
             x = pool.get(S // 4, S // 4, 64)
+            if os.environ.get("ASL_NO_FUSED_STEM"):
+                a = pool.get(S // 2, S // 2, 64)
+                stem_op(self._w["stem"], x0, in_halo, a, 2, 3, True)
 
-            def maxpool(n, stream, a=a, x=x):
-                L.check(L.lib.asl_maxpool3x3s2_nhwc(_ptr(a.t), n, a.h, a.w, a.c, a.halo, _ptr(x.t), x.halo, stream),
-                        "maxpool")
-            ops.append(maxpool)
-            pool.put(a)
+                def maxpool(n, stream, a=a, x=x):
+                    L.check(L.lib.asl_maxpool3x3s2_nhwc(_ptr(a.t), n, a.h, a.w, a.c, a.halo, _ptr(x.t), x.halo, stream),
+                            "maxpool")
+                ops.append(maxpool)
+                pool.put(a)
+            else:
+                pc = self._w["stem"]
+                sp = L.StemPoolParams(n=0, h=S, w=S, cout=pc.cout, out_halo=x.halo, w_rows=pc.w_rows)
+                sargs = (_ptr(x0), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(x.t))
+
+                def run(n, stream, sp=sp, sargs=sargs, keep=(x0, x, pc)):
+                    sp.n = n
+                    L.check(L.lib.asl_stem_pool_bf16(C.byref(sp), *sargs, stream), "stem+pool")
+                ops.append(run)
             basic = RESNET_LAYERS[spec.backbone][0] == "basic"
             for prefix, cin, planes, stride, ds in resnet_blocks(spec.backbone):
                 oh, ow = x.h // stride, x.w // stride
