@@ -1,0 +1,28 @@
+// Diagnostic: per-workgroup phase times of the patch conv (needs a library built with -DASL_STAMPS).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include "asl_hip.h"
+int main(int argc, char** argv) {
+    const int frames = 512, hw = argc > 1 ? atoi(argv[1]) : 56, c = argc > 2 ? atoi(argv[2]) : 64;
+    const int hp = hw + 2;
+    size_t xe = (size_t)frames * hp * hp * c, we = (size_t)((c + 127) / 128 * 128) * 9 * c;
+    void *x, *y, *r, *w; unsigned long long* st;
+    hipMalloc(&x, xe * 2); hipMalloc(&y, xe * 2); hipMalloc(&r, xe * 2); hipMalloc(&w, we * 2);
+    hipMemset(x, 0, xe * 2); hipMemset(r, 0, xe * 2); hipMemset(w, 0, we * 2); hipMemset(y, 0, xe * 2);
+    const size_t nst = 200000; hipMalloc(&st, nst * 5 * 8); hipMemset(st, 0, nst * 5 * 8);
+    char buf[64]; snprintf(buf, sizeof buf, "%llx", (unsigned long long)st); setenv("ASL_STAMP_PTR", buf, 1);
+    asl_conv2d_params p = {};
+    p.n = frames; p.h = p.w = hw; p.cin = c; p.in_halo = 1; p.cout = c; p.kh = p.kw = 3; p.stride = 1; p.pad = 1;
+    p.out_halo = 1; p.out_ctot = c; p.res_halo = 1; p.res_ctot = c; p.relu = 1; p.w_rows = (c + 127) / 128 * 128;
+    for (int it = 0; it < 3; ++it) { int rc = asl_conv2d_nhwc_bf16(&p, x, w, nullptr, nullptr, r, y, nullptr); if (rc) { printf("rc %d\n", rc); return 1; } }
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(nst * 5);
+    hipMemcpy(h.data(), st, nst * 5 * 8, hipMemcpyDeviceToHost);
+    double s[4] = {0, 0, 0, 0}; size_t n = 0; unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t b = 0; b < nst; ++b) { if (!h[b * 5]) continue; ++n; for (int k = 0; k < 4; ++k) s[k] += (double)(h[b * 5 + k + 1] - h[b * 5 + k]); t0 = std::min(t0, h[b * 5]); t1 = std::max(t1, h[b * 5 + 4]); }
+    printf("%dx%d c%d: %zu workgroups; mean cycles: prologue %.0f, K loop %.0f, epilogue %.0f, store drain %.0f; kernel span %.0f cycles\n", hw, hw, c, n, s[0] / n, s[1] / n, s[2] / n, s[3] / n, (double)(t1 - t0));
+    return 0;
+}

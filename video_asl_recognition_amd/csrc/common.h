@@ -29,3 +29,25 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Division of a 32-bit unsigned by a divisor fixed at launch: multiply-high + shifts instead of the
+// ~40-instruction hardware-less integer division (Granlund-Montgomery round-up method, exact for all n).
+struct FastDiv {
+    unsigned d, mul, s1, s2;
+};
+
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l < 1 ? 0 : l - 1;
+    return f;
+}
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+    const unsigned t = __umulhi(f.mul, n);
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}

@@ -27,11 +27,13 @@ constexpr int kPatchPixels = 432;
 constexpr int kPatchBytes = kPatchPixels * 128;
 constexpr int kStages = 3;                    // weight ring depth: prefetch distance 2
 
-// 4 waves; workgroup tile = up to 256 pixel slots x 64 output channels; each wave 64 slots x 64 channels
-__global__ __launch_bounds__(256) void conv3x3_patch_kernel(const PatchArgs a) {
+// NW waves; workgroup tile = up to 256 pixel slots x 64 output channels; each wave 256/NW slots x 64 channels
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BN = 64, NW = 4;
-    constexpr int FM = 4, FN = 4;
+    constexpr int BN = 64;
+    constexpr int WTM = 256 / NW;
+    constexpr int FM = WTM / 16, FN = 4;
     constexpr int W_BYTES = BN * 128;                 // one (chunk, tap) weight stage
     constexpr int W_PW = W_BYTES / 1024 / NW;         // LDS-DMA instructions per wave per stage (2)
 
@@ -40,6 +42,10 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const PatchArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if defined(ASL_STAMPS)
+    unsigned long long st[5];
+    st[0] = __builtin_amdgcn_s_memtime();
+#endif
 
     int lbid;
     {
@@ -61,8 +67,8 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const PatchArgs a) {
 
     // centre pixel (in halo'd, image-major pixel units) of output pixel m
     auto centre = [&](int m) -> long long {
-        const int n = m / HW, r1 = m - n * HW;
-        const int y = r1 / a.W, x = r1 - y * a.W;
+        const int n = (int)fdiv(m, a.dOHW), r1 = m - n * HW;
+        const int y = (int)fdiv(r1, a.dOW), x = r1 - y * a.W;
         return ((long long)n * a.Hp + y + a.in_halo) * a.Wp + x + a.in_halo;
     };
     const int mend = (m0 + a.bmv < a.M ? m0 + a.bmv : a.M);           // one past this tile's last pixel
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const PatchArgs a) {
     int pc[FM];                                   // patch-local centre pixel of this lane's pixel, per fragment
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        int m = m0 + wave * 64 + i * 16 + fr;
+        int m = m0 + wave * WTM + i * 16 + fr;
         m = m < mend ? m : mend - 1;              // idle slots recompute the tile's last pixel; never stored
         pc[i] = (int)(centre(m) - P0);
     }
@@ -143,6 +149,9 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const PatchArgs a) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
+#if defined(ASL_STAMPS)
+    st[1] = __builtin_amdgcn_s_memtime();
+#endif
     int tap = 0, chunk = 0;
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
@@ -191,16 +200,26 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(const PatchArgs a) {
 #if defined(ASL_ABL_NOEPI)
     if (a.M > 0) { if (acc[0][0][0] == 123.456f) a.y[0] = 1; return; }
 #endif
+#if defined(ASL_STAMPS)
+    st[2] = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue: the staging LDS overlays the patch; the loop's last barrier frees it ------------
     OutGeom g;
     g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = mend; g.N = a.N;
-    g.OW = a.OW; g.OHW = a.OHW; g.ODHW = a.ODHW;
+    g.dOW = a.dOW; g.dOHW = a.dOHW; g.dODHW = a.dODHW;
     g.out_sn = a.out_sn; g.out_sd = 0; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
     g.res_sn = a.res_sn; g.res_sd = 0; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
     g.relu = a.relu; g.out_f32 = 0; g.res_f32 = 0;
     static_assert(NW * kEpiWaveBytes(FN * 16) <= kPatchBytes, "epilogue stage does not fit the patch buffer");
-    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(FN * 16), g, m0 + wave * 64, tn * BN, lane);
+    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(FN * 16), g, m0 + wave * WTM, tn * BN, lane);
+#if defined(ASL_STAMPS)
+    st[3] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[4] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && tid == 0)
+        for (int k = 0; k < 5; ++k) a.stamps[(long long)blockIdx.x * 5 + k] = st[k];
+#endif
 #endif
 }
 
@@ -240,6 +259,10 @@ int patch_conv_tile(int n, int h, int w, int in_halo) {
 }
 
 int launch_conv3x3_patch(PatchArgs a, hipStream_t stream) {
+    // the kernel trusts these; refuse anything inconsistent rather than index with it
+    if (a.W <= 0 || a.H <= 0 || (int)a.dOW.d != a.W || (int)a.dOHW.d != a.H * a.W || a.bmv <= 0 || a.bmv > 256 ||
+        a.nchunks * 64 != a.C || a.Wp != a.W + 2 * a.in_halo || a.Hp != a.H + 2 * a.in_halo)
+        return ASL_EINVAL;
     a.tiles_m = (a.M + a.bmv - 1) / a.bmv;
     a.tiles_n = (a.N + 63) / 64;
     // 100 MHz ticks: ~0.2 us per K step is half of a tile's measured duration; only worth it when the
@@ -249,9 +272,13 @@ int launch_conv3x3_patch(PatchArgs a, hipStream_t stream) {
     if (const char* e = getenv("ASL_STAGGER_TICKS")) a.stagger_ticks = atoi(e);
     int lds = kPatchBytes + kStages * 64 * 128;
     if (const char* e2 = getenv("ASL_PATCH_LDS_PAD")) lds += atoi(e2);
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    // single-chunk layers (C = 64) are prologue/epilogue-bound: 8 waves split that work finer
+    const bool w8 = a.nchunks == 1 && !getenv("ASL_PATCH_4WAVES");
+    hipError_t e = hipFuncSetAttribute(w8 ? (const void*)conv3x3_patch_kernel<8> : (const void*)conv3x3_patch_kernel<4>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(conv3x3_patch_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), lds, stream, a);
+    if (w8) hipLaunchKernelGGL(conv3x3_patch_kernel<8>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL(conv3x3_patch_kernel<4>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), lds, stream, a);
     return (int)hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ struct OutGeom {
     const char* res;
     char* y;
     int M, N;
-    int OW, OHW, ODHW;                 // output grid decomposition of row m
+    FastDiv dOW, dOHW, dODHW;          // output grid decomposition of row m (divisors OW, OH*OW, OD*OH*OW)
     long long out_sn, res_sn;
     int out_sd, out_sh, out_sw, out_off0;
     int res_sd, res_sh, res_sw, res_off0;
@@ -58,9 +58,9 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char*
             const int m = m_wave0 + i * 16 + ps * PPI + pr0;
             ok[i][ps] = m < g.M && ch < g.N;
             const int mm = m < g.M ? m : g.M - 1;
-            const int n = mm / g.ODHW, r1 = mm - n * g.ODHW;
-            const int d = r1 / g.OHW, r2 = r1 - d * g.OHW;
-            const int h = r2 / g.OW, w_ = r2 - h * g.OW;
+            const int n = (int)fdiv(mm, g.dODHW), r1 = mm - n * (int)g.dODHW.d;
+            const int d = (int)fdiv(r1, g.dOHW), r2 = r1 - d * (int)g.dOHW.d;
+            const int h = (int)fdiv(r2, g.dOW), w_ = r2 - h * (int)g.dOW.d;
             oe[i][ps] = (long long)n * g.out_sn + (long long)d * g.out_sd + (long long)h * g.out_sh +
                         (long long)w_ * g.out_sw + g.out_off0 + ch;
             re[i][ps] = 0;

@@ -28,7 +28,7 @@ struct GemmArgs {
     const char* res;
     char* y;
     int M, N;
-    int OHW, ODHW, OW;
+    FastDiv dOW, dOHW, dODHW;
     long long in_sn, out_sn, res_sn;
     int in_sd, in_sh, in_sw, in_off0;
     int out_sd, out_sh, out_sw, out_off0;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
     }
     const int tn = lbid % a.tiles_n, tm = lbid / a.tiles_n;
     const int m0 = tm * BM;
-    const int n0img = m0 / a.ODHW;      // first image this tile touches (block-uniform)
+    const int n0img = (int)fdiv(m0, a.dODHW);      // first image this tile touches (block-uniform)
 
     // ---- LDS-DMA source offsets: fixed per lane for the whole K loop --------------------
     const char* xbase = a.x + 2 * (long long)n0img * a.in_sn;
@@ -104,9 +104,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
         const int chunk = (lane % CPR) ^ swz<BK>(row);
         const int m = m0 + row;
         if (m < a.M) {
-            const int n = m / a.ODHW, r1 = m - n * a.ODHW;
-            const int d = r1 / a.OHW, r2 = r1 - d * a.OHW;
-            const int h = r2 / a.OW, w_ = r2 - h * a.OW;
+            const int n = (int)fdiv(m, a.dODHW), r1 = m - n * (int)a.dODHW.d;
+            const int d = (int)fdiv(r1, a.dOHW), r2 = r1 - d * (int)a.dOHW.d;
+            const int h = (int)fdiv(r2, a.dOW), w_ = r2 - h * (int)a.dOW.d;
             const long long e = (long long)(n - n0img) * a.in_sn + (long long)d * a.in_sd +
                                 (long long)h * a.in_sh + (long long)w_ * a.in_sw + a.in_off0;
             xvoff[i] = (unsigned)(2 * e + 16 * chunk);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
     // ---- epilogue (the loop's last barrier guarantees every wave is done reading the stages) -----
     OutGeom g;
     g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = a.M; g.N = a.N;
-    g.OW = a.OW; g.OHW = a.OHW; g.ODHW = a.ODHW;
+    g.dOW = a.dOW; g.dOHW = a.dOHW; g.dODHW = a.dODHW;
     g.out_sn = a.out_sn; g.out_sd = a.out_sd; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
     g.res_sn = a.res_sn; g.res_sd = a.res_sd; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
     g.relu = a.relu; g.out_f32 = a.out_f32; g.res_f32 = a.res_f32;
@@ -280,7 +280,7 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
     a.x = (const char*)x; a.w = (const char*)w; a.scale = scale; a.bias = bias;
     a.res = (const char*)res; a.y = (char*)y;
     a.M = (int)M; a.N = p->cout;
-    a.OW = p->ow; a.OHW = p->oh * p->ow; a.ODHW = p->od * p->oh * p->ow;
+    a.dOW = make_fastdiv(p->ow); a.dOHW = make_fastdiv(p->oh * p->ow); a.dODHW = make_fastdiv(p->od * p->oh * p->ow);
     a.in_sn = p->in.sn; a.in_sd = p->in.sd; a.in_sh = p->in.sh; a.in_sw = p->in.sw; a.in_off0 = p->in.off0;
     a.out_sn = p->out.sn; a.out_sd = p->out.sd; a.out_sh = p->out.sh; a.out_sw = p->out.sw; a.out_off0 = p->out.off0;
     a.res_sn = p->res.sn; a.res_sd = p->res.sd; a.res_sh = p->res.sh; a.res_sw = p->res.sw; a.res_off0 = p->res.off0;
@@ -301,13 +301,17 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
         int bmv = 0;
         if (halo >= 1 && Wp == p->ow + 2 * halo && Hp == p->oh + 2 * halo &&
             p->in.off0 == ((halo - 1) * Wp + (halo - 1)) * C && (bmv = patch_conv_tile(p->nb, p->oh, p->ow, halo)) > 0) {
-            PatchArgs b;
+            PatchArgs b = {};
             b.x = a.x; b.w = a.w; b.scale = a.scale; b.bias = a.bias; b.res = a.res; b.y = a.y;
             b.M = a.M; b.N = a.N; b.H = p->oh; b.W = p->ow; b.Hp = Hp; b.Wp = Wp; b.in_halo = halo;
             b.C = C; b.nchunks = C / 64; b.bmv = bmv; b.wk = a.wk; b.x_bytes = a.x_bytes; b.w_bytes = a.w_bytes;
             b.out_sn = a.out_sn; b.out_sh = a.out_sh; b.out_sw = a.out_sw; b.out_off0 = a.out_off0;
             b.res_sn = a.res_sn; b.res_sh = a.res_sh; b.res_sw = a.res_sw; b.res_off0 = a.res_off0;
-            b.relu = a.relu; b.tiles_m = b.tiles_n = 0; b.OW = a.OW; b.OHW = a.OHW; b.ODHW = a.ODHW;
+            b.relu = a.relu; b.tiles_m = b.tiles_n = 0; b.stamps = nullptr;
+#if defined(ASL_STAMPS)
+            if (const char* e = getenv("ASL_STAMP_PTR")) b.stamps = (unsigned long long*)strtoull(e, nullptr, 16);
+#endif
+            b.dOW = a.dOW; b.dOHW = a.dOHW; b.dODHW = a.dODHW;
             return launch_conv3x3_patch(b, s);
         }
     }

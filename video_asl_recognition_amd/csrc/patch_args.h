@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "common.h"
+
 namespace asl_detail {
 
 struct PatchArgs {
@@ -23,8 +25,9 @@ struct PatchArgs {
     int out_sh, out_sw, out_off0;
     int res_sh, res_sw, res_off0;
     int relu;
-    int OW, OHW, ODHW;
+    FastDiv dOW, dOHW, dODHW;   // divisors W, H*W, H*W (od == 1)
     int tiles_m, tiles_n;
+    unsigned long long* stamps;   // diagnostic builds only (ASL_STAMPS): 5 s_memtime stamps per workgroup
     int stagger_ticks;     // one-time start delay (100 MHz ticks) of the second resident workgroup set
 };
 
