@@ -137,6 +137,17 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- output coordinates and residual loads first: the oldest loads in flight, they retire under the
+    // prologue's first counted wait and cost the epilogue nothing
+    OutGeom g;
+    g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = mend; g.N = a.N;
+    g.dOW = a.dOW; g.dOHW = a.dOHW; g.dODHW = a.dODHW;
+    g.out_sn = a.out_sn; g.out_sd = 0; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
+    g.res_sn = a.res_sn; g.res_sd = 0; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
+    g.relu = a.relu; g.out_f32 = 0; g.res_f32 = 0;
+    EpiState<FM, FN> est;
+    epilogue_prepare<FM, FN>(est, g, m0 + wave * WTM, tn * BN, lane);
+
     // ---- prologue: patch of chunk 0, weights of steps 0 and 1 ----------------------------------
     // Waits are counted: vmcnt(W_PW) retires everything but the youngest weight stage, so one stage stays
     // in flight across every barrier.  The barrier is raw (inside the asm) so hipcc adds no vmcnt(0).
@@ -205,14 +216,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
 #endif
 
     // ---- epilogue: the staging LDS overlays the patch; the loop's last barrier frees it ------------
-    OutGeom g;
-    g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = mend; g.N = a.N;
-    g.dOW = a.dOW; g.dOHW = a.dOHW; g.dODHW = a.dODHW;
-    g.out_sn = a.out_sn; g.out_sd = 0; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
-    g.res_sn = a.res_sn; g.res_sd = 0; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
-    g.relu = a.relu; g.out_f32 = 0; g.res_f32 = 0;
     static_assert(NW * kEpiWaveBytes(FN * 16) <= kPatchBytes, "epilogue stage does not fit the patch buffer");
-    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(FN * 16), g, m0 + wave * WTM, tn * BN, lane);
+    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(FN * 16), g, est, lane);
 #if defined(ASL_STAMPS)
     st[3] = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -26,73 +26,93 @@ struct OutGeom {
 constexpr int kEpiRowBytes(int wtn) { return wtn * 4 + 16; }          // fp32 row + 16 B pad
 constexpr int kEpiWaveBytes(int wtn) { return 16 * kEpiRowBytes(wtn); }
 
+// Per-lane output coordinates and the residual values of an epilogue, computed (and the residual loads
+// issued) BEFORE the K loop so their latency hides under it.  Lane (g8, pr0) of a wave handles channels
+// ch..ch+7 of pixels pr0, pr0 + PPI, ... of every 16-pixel fragment.
+template <int FM, int FN>
+struct EpiState {
+    static constexpr int WTN = FN * 16;
+    static constexpr int G8 = WTN / 8;            // 8-channel groups per pixel row of the wave tile
+    static constexpr int PPI = 64 / G8;           // pixels covered per pass of 64 lanes
+    static constexpr int PASSES = 16 / PPI;
+    long long oe[FM][PASSES];                     // output element offset (channel ch of the pixel)
+    long long re[FM][PASSES];                     // residual element offset
+    bf16x8 r8[FM][PASSES];                        // bf16 residual values (zeros when there is no residual)
+    unsigned okmask;                              // bit i*PASSES+ps: this lane stores that pixel
+    int ch;
+    bool full;                                    // ch..ch+7 all < N
+};
+
+template <int FM, int FN>
+__device__ __forceinline__ void epilogue_prepare(EpiState<FM, FN>& st, const OutGeom& g, int m_wave0, int ch_wave0,
+                                                 int lane) {
+    using S = EpiState<FM, FN>;
+    const int g8 = lane % S::G8, pr0 = lane / S::G8;
+    st.ch = ch_wave0 + g8 * 8;
+    st.full = st.ch + 7 < g.N;
+    st.okmask = 0;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int ps = 0; ps < S::PASSES; ++ps) {
+            const int m = m_wave0 + i * 16 + ps * S::PPI + pr0;
+            const bool ok = m < g.M && st.ch < g.N;
+            if (ok) st.okmask |= 1u << (i * S::PASSES + ps);
+            const int mm = m < g.M ? m : g.M - 1;
+            const int n = (int)fdiv(mm, g.dODHW), r1 = mm - n * (int)g.dODHW.d;
+            const int d = (int)fdiv(r1, g.dOHW), r2 = r1 - d * (int)g.dOHW.d;
+            const int h = (int)fdiv(r2, g.dOW), w_ = r2 - h * (int)g.dOW.d;
+            st.oe[i][ps] = (long long)n * g.out_sn + (long long)d * g.out_sd + (long long)h * g.out_sh +
+                           (long long)w_ * g.out_sw + g.out_off0 + st.ch;
+            st.re[i][ps] = 0;
+            st.r8[i][ps] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (g.res) {
+                st.re[i][ps] = (long long)n * g.res_sn + (long long)d * g.res_sd + (long long)h * g.res_sh +
+                               (long long)w_ * g.res_sw + g.res_off0 + st.ch;
+                if (ok && st.full && !g.res_f32) st.r8[i][ps] = *(const bf16x8*)(g.res + 2 * st.re[i][ps]);
+            }
+        }
+}
+
 // acc[i][j]: 16x16 tile (pixel fragment i, channel fragment j); lane holds channels 4*(lane>>4)..+3
 // of pixel (lane & 15).  `stage` is this wave's private LDS region of kEpiWaveBytes(FN*16) bytes; the
 // caller guarantees no other wave still reads the LDS it overlays.
 template <int FM, int FN>
 __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char* stage, const OutGeom& g,
-                                               int m_wave0, int ch_wave0, int lane) {
-    constexpr int WTN = FN * 16;
-    constexpr int ROWB = kEpiRowBytes(WTN);
-    constexpr int G8 = WTN / 8;                  // 8-channel groups per pixel row of the wave tile
-    constexpr int PPI = 64 / G8;                 // pixels covered per pass of 64 lanes
-    constexpr int PASSES = 16 / PPI;
+                                               const EpiState<FM, FN>& st, int lane) {
+    using S = EpiState<FM, FN>;
+    constexpr int ROWB = kEpiRowBytes(S::WTN);
     const int fr = lane & 15, fq = lane >> 4;
-    const int g8 = lane % G8, pr0 = lane / G8;
-    const int ch = ch_wave0 + g8 * 8;
-    const bool full = ch + 7 < g.N;
+    const int g8 = lane % S::G8, pr0 = lane / S::G8;
+    const int ch = st.ch;
+    const bool full = st.full;
     f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
     if (full) {
         if (g.scale) { s0 = *(const f32x4*)(g.scale + ch); s1 = *(const f32x4*)(g.scale + ch + 4); }
         if (g.bias) { b0 = *(const f32x4*)(g.bias + ch); b1 = *(const f32x4*)(g.bias + ch + 4); }
     }
-    // output / residual element offsets of this lane's (fragment, pass) pixels; every residual load is
-    // issued here, ahead of the staging loop, so their latencies overlap instead of adding up
-    long long oe[FM][PASSES], re[FM][PASSES];
-    bool ok[FM][PASSES];
-    bf16x8 r8[FM][PASSES];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int m = m_wave0 + i * 16 + ps * PPI + pr0;
-            ok[i][ps] = m < g.M && ch < g.N;
-            const int mm = m < g.M ? m : g.M - 1;
-            const int n = (int)fdiv(mm, g.dODHW), r1 = mm - n * (int)g.dODHW.d;
-            const int d = (int)fdiv(r1, g.dOHW), r2 = r1 - d * (int)g.dOHW.d;
-            const int h = (int)fdiv(r2, g.dOW), w_ = r2 - h * (int)g.dOW.d;
-            oe[i][ps] = (long long)n * g.out_sn + (long long)d * g.out_sd + (long long)h * g.out_sh +
-                        (long long)w_ * g.out_sw + g.out_off0 + ch;
-            re[i][ps] = 0;
-            r8[i][ps] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (g.res) {
-                re[i][ps] = (long long)n * g.res_sn + (long long)d * g.res_sd + (long long)h * g.res_sh +
-                            (long long)w_ * g.res_sw + g.res_off0 + ch;
-                if (ok[i][ps] && full && !g.res_f32) r8[i][ps] = *(const bf16x8*)(g.res + 2 * re[i][ps]);
-            }
-        }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) *(f32x4*)(stage + fr * ROWB + (j * 16 + fq * 4) * 4) = acc[i][j];
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int pr = ps * PPI + pr0;
+        for (int ps = 0; ps < S::PASSES; ++ps) {
+            const int pr = ps * S::PPI + pr0;
             f32x4 v0 = *(const f32x4*)(stage + pr * ROWB + g8 * 32);
             f32x4 v1 = *(const f32x4*)(stage + pr * ROWB + g8 * 32 + 16);
-            if (!ok[i][ps]) continue;
-            const long long o = oe[i][ps];
+            if (!((st.okmask >> (i * S::PASSES + ps)) & 1)) continue;
+            const long long o = st.oe[i][ps];
             if (full) {
                 v0 = v0 * s0 + b0;
                 v1 = v1 * s1 + b1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v0[e] += bf16_to_f32(r8[i][ps][e]);
-                    v1[e] += bf16_to_f32(r8[i][ps][4 + e]);
+                    v0[e] += bf16_to_f32(st.r8[i][ps][e]);
+                    v1[e] += bf16_to_f32(st.r8[i][ps][4 + e]);
                 }
                 if (g.res && g.res_f32) {          // fp32 residual stream (small GEMMs only): loaded in place
-                    v0 += *(const f32x4*)(g.res + 4 * re[i][ps]);
-                    v1 += *(const f32x4*)(g.res + 4 * re[i][ps] + 16);
+                    v0 += *(const f32x4*)(g.res + 4 * st.re[i][ps]);
+                    v1 += *(const f32x4*)(g.res + 4 * st.re[i][ps] + 16);
                 }
                 if (g.relu) {
 #pragma unroll
@@ -112,8 +132,8 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char*
                     float t = e < 4 ? v0[e & 3] : v1[e & 3];
                     if (g.scale) t *= g.scale[ch + e];
                     if (g.bias) t += g.bias[ch + e];
-                    if (g.res) t += g.res_f32 ? *(const float*)(g.res + 4 * (re[i][ps] + e))
-                                              : bf16_to_f32(*(const short*)(g.res + 2 * (re[i][ps] + e)));
+                    if (g.res) t += g.res_f32 ? *(const float*)(g.res + 4 * (st.re[i][ps] + e))
+                                              : bf16_to_f32(*(const short*)(g.res + 2 * (st.re[i][ps] + e)));
                     if (g.relu) t = fmaxf(t, 0.f);
                     if (g.out_f32) *(float*)(g.y + 4 * (o + e)) = t;
                     else *(short*)(g.y + 2 * (o + e)) = f32_to_bf16(t);

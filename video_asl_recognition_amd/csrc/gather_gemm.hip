@@ -176,6 +176,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // output coordinates and residual loads first: they complete under the K loop
+    OutGeom g;
+    g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = a.M; g.N = a.N;
+    g.dOW = a.dOW; g.dOHW = a.dOHW; g.dODHW = a.dODHW;
+    g.out_sn = a.out_sn; g.out_sd = a.out_sd; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
+    g.res_sn = a.res_sn; g.res_sd = a.res_sd; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
+    g.relu = a.relu; g.out_f32 = a.out_f32; g.res_f32 = a.res_f32;
+    EpiState<FM, FN> est;
+    epilogue_prepare<FM, FN>(est, g, m0 + wm * WTM, tn * BN + wn * WTN, lane);
+
     const int nsteps = a.ntaps * a.ksteps_per_tap;
     stage(0);
     wait_vm0();
@@ -203,14 +213,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
     }
 
     // ---- epilogue (the loop's last barrier guarantees every wave is done reading the stages) -----
-    OutGeom g;
-    g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = a.M; g.N = a.N;
-    g.dOW = a.dOW; g.dOHW = a.dOHW; g.dODHW = a.dODHW;
-    g.out_sn = a.out_sn; g.out_sd = a.out_sd; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
-    g.res_sn = a.res_sn; g.res_sd = a.res_sd; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
-    g.relu = a.relu; g.out_f32 = a.out_f32; g.res_f32 = a.res_f32;
     static_assert(NW * kEpiWaveBytes(WTN) <= 2 * BUF, "epilogue stage does not fit the K-loop LDS");
-    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(WTN), g, m0 + wm * WTM, tn * BN + wn * WTN, lane);
+    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(WTN), g, est, lane);
 #endif
 }
 
