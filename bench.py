@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--clips", type=int, default=8, help="clips per GPU per step")
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("ASL_CHUNK", "256")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("ASL_STREAMS", "2")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -66,7 +67,7 @@ def main():
 
     spec = SPECS["resnet18_mean"]
     B, T, S = args.clips, args.frames, spec.size
-    model = AslClipModel(spec, device=str(dev), frames_per_chunk=args.chunk)
+    model = AslClipModel(spec, device=str(dev), frames_per_chunk=args.chunk, streams=args.streams)
     use_oracle = rank == 0 and world == 1 and not args.no_cpu_baseline
     oracle = None
     if use_oracle:
@@ -127,7 +128,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "resnet18_mean: ResNet-18 per frame + mean over T + Linear(512,100), "
                                    f"T={T}, {S}x{S}, {B} clips/GPU/step, random-init weights, clips resident in HBM",
-                       "clips_per_gpu": B, "frames_per_clip": T, "frames_per_chunk": args.chunk,
+                       "clips_per_gpu": B, "frames_per_clip": T, "frames_per_chunk": args.chunk, "streams": args.streams,
                        "parallelism": f"batch-sharded x{world}, all-gather of logits"},
             "roofline": {
                 "bound": "mfma",
@@ -155,8 +156,8 @@ def time_conv_launches(model, clips, passes=3):
     """Sum of the gather-GEMM launch durations of one step (ms) and their count, from events
     recorded around each conv launch on the launch stream."""
     import ctypes as C
-    plan = model._get_plan(clips.shape[0] * clips.shape[1])
     n_total = clips.shape[0] * clips.shape[1]
+    plan = model._get_plans(min(n_total, model.frames_per_chunk), 1)[0]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     conv_ops = [op for op in plan["ops"] if op.__name__ == "run"]
     best = None

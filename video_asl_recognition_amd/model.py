@@ -70,12 +70,15 @@ class _BufPool:
 
 
 class AslClipModel:
-    def __init__(self, spec, device: str = "cuda", frames_per_chunk: int = 256, seed: Optional[int] = None):
+    def __init__(self, spec, device: str = "cuda", frames_per_chunk: int = 256, seed: Optional[int] = None,
+                 streams: int = 2):
         self.spec: ModelSpec = SPECS[spec] if isinstance(spec, str) else spec
         if not torch.cuda.is_available():
             raise RuntimeError("AslClipModel needs an MI355X (no GPU visible); there is no CPU path")
         self.device = torch.device(device)
         self.frames_per_chunk = int(frames_per_chunk)
+        self.streams = int(streams)
+        self._streams: List[torch.cuda.Stream] = []
         self._plan = None
         self._w: Dict[str, PackedConv] = {}
         self._fc_w = self._fc_b = None
@@ -226,16 +229,13 @@ class AslClipModel:
         plan = {"x0": x0, "in_halo": in_halo, "ops": ops, "last": x, "pool": pool, "nmax": nmax}
         return plan
 
-    def _get_plan(self, n: int):
-        nmax = min(n, self.frames_per_chunk)
-        if self._plan is None or self._plan["nmax"] < nmax:
-            self._plan = self._build_plan(nmax)
-        return self._plan
-
     # ------------------------------------------------------------------ backbone
     def _run_backbone(self, n_total: int, fill_x0, want_bf16: bool):
-        """fill_x0(c0, n, x0, in_halo, stream) writes frames [c0, c0+n) into the packed stem input."""
-        plan = self._get_plan(n_total)
+        """fill_x0(c0, n, x0, in_halo, stream) writes frames [c0, c0+n) into the packed stem input.
+
+        Chunks alternate between `self.streams` HIP streams (each with its own workspace), so one
+        chunk's kernels fill the CUs another chunk's kernel leaves idle in its last, partial round of
+        workgroups and during its per-tile load/store phases."""
         F = self.spec.feat_dim
         feats = torch.empty(n_total, F, dtype=torch.float32, device=self.device)
         # bf16 copy of the features = GEMM operand of the temporal encoder; the two-stream model appends
@@ -246,18 +246,39 @@ class AslClipModel:
         if self.spec.temporal == "bilstm":
             ld_b, lo_off = 2 * F, F
         feats_b = torch.empty(n_total, ld_b, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        last: Act = plan["last"]
-        step = plan["nmax"]
-        for c0 in range(0, n_total, step):
+        nstreams = max(1, min(self.streams, (n_total + self.frames_per_chunk - 1) // self.frames_per_chunk))
+        step = min(self.frames_per_chunk, (n_total + nstreams - 1) // nstreams)
+        plans = self._get_plans(step, nstreams)
+        main = torch.cuda.current_stream()
+        side = self._side_streams(nstreams)
+        for s_ in side:
+            s_.wait_stream(main)
+        for k, c0 in enumerate(range(0, n_total, step)):
+            plan = plans[k % nstreams]
+            st = main if nstreams == 1 else side[k % nstreams]
+            stream = C.c_void_p(st.cuda_stream)
             n = min(step, n_total - c0)
             fill_x0(c0, n, plan["x0"], plan["in_halo"], stream)
             for op in plan["ops"]:
                 op(n, stream)
+            last: Act = plan["last"]
             fb = None if feats_b is None else C.c_void_p(feats_b.data_ptr() + c0 * ld_b * 2)
             L.check(L.lib.asl_avgpool_nhwc(_ptr(last.t), n, last.h, last.w, last.c, last.halo,
                                            C.c_void_p(feats.data_ptr() + c0 * F * 4), fb, ld_b, lo_off, stream), "avgpool")
+        if nstreams > 1:
+            for s_ in side:
+                main.wait_stream(s_)
         return feats, feats_b
+
+    def _side_streams(self, n):
+        while len(self._streams) < n:
+            self._streams.append(torch.cuda.Stream(device=self.device))
+        return self._streams[:n]
+
+    def _get_plans(self, nmax: int, count: int):
+        if self._plan is None or self._plan[0]["nmax"] < nmax or len(self._plan) < count:
+            self._plan = [self._build_plan(nmax) for _ in range(count)]
+        return self._plan
 
     def frame_features(self, clips: torch.Tensor, want_bf16: bool = False):
         """clips [B,T,3,S,S] -> per-frame features fp32 [B*T, F] (and their bf16 copy)."""
@@ -403,8 +424,8 @@ class AslClipModel:
     def workspace_bytes(self) -> int:
         if self._plan is None:
             return 0
-        if isinstance(self._plan, dict):
-            return self._plan["pool"].nbytes() + self._plan["x0"].numel() * 2
+        if isinstance(self._plan, list):
+            return sum(p["pool"].nbytes() + p["x0"].numel() * 2 for p in self._plan)
         return self._plan.nbytes()
 
 
