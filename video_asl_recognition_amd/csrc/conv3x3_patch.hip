@@ -27,21 +27,30 @@ constexpr int kPatchPixels = 432;
 constexpr int kPatchBytes = kPatchPixels * 128;
 constexpr int kStages = 3;                    // weight ring depth: prefetch distance 2
 
-// NW waves; workgroup tile = up to 256 pixel slots x 64 output channels; each wave 256/NW slots x 64 channels
-template <int NW>
+// NW waves; workgroup tile = up to 256 pixel slots x BN output channels, waves laid out (NW / (BN/64)) x (BN/64),
+// each wave a (256 / rows of waves) x 64 tile.  A 64x64 wave tile reads as many LDS bytes per MFMA as the LDS
+// pipe can deliver at the MFMA peak rate; the BN = 128 shape gives each wave 128 pixels x 64 channels (a third
+// fewer fragment reads per MFMA) and pays for it with K steps of 32 channels so a weight stage stays 8 KiB.
+template <int NW, int BN>
 __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BN = 64;
-    constexpr int WTM = 256 / NW;
+    constexpr int WGN = BN / 64, WGM = NW / WGN;
+    constexpr int WTM = 256 / WGM;
     constexpr int FM = WTM / 16, FN = 4;
-    constexpr int W_BYTES = BN * 128;                 // one (chunk, tap) weight stage
-    constexpr int W_PW = W_BYTES / 1024 / NW;         // LDS-DMA instructions per wave per stage (2)
+    constexpr int KS = BN == 64 ? 64 : 32;            // input channels per K step
+    constexpr int KK = KS / 32, SPT = 64 / KS;        // MFMA k-slices per step; steps per (chunk, tap)
+    constexpr int RB = KS * 2, CPR = RB / 16, RPI = 64 / CPR;   // staged weight row: bytes, 16-B chunks, rows per DMA
+    constexpr int W_BYTES = BN * RB;                  // one weight stage (8 KiB)
+    constexpr int W_PW = W_BYTES / 1024 / NW;         // LDS-DMA instructions per wave per stage
+    static_assert(W_PW >= 1 && W_PW * NW * 1024 == W_BYTES, "weight stage / wave count mismatch");
+    auto wswz = [](int row) { return KS == 64 ? ((row >> 1) & 7) : ((row & 8) ? 3 : 0); };
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wst = smem + kPatchBytes;              // weight ring follows the patch
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
 #if defined(ASL_STAMPS)
     unsigned long long st[5];
     st[0] = __builtin_amdgcn_s_memtime();
@@ -93,8 +102,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
     unsigned wvoff[W_PW];
 #pragma unroll
     for (int i = 0; i < W_PW; ++i) {
-        const int row = (wave * W_PW + i) * 8 + (lane >> 3);
-        wvoff[i] = (unsigned)(2 * row * a.wk + 16 * ((lane & 7) ^ ((row >> 1) & 7)));
+        const int row = (wave * W_PW + i) * RPI + lane / CPR;
+        wvoff[i] = (unsigned)(2 * row * a.wk + 16 * ((lane % CPR) ^ wswz(row)));
     }
     auto dma_patch = [&](int chunk) {
         for (int i = wave; i < NPI; i += NW) {
@@ -103,10 +112,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
                                                      pvoff0 ^ ((unsigned)(i & 1) << 6), so, 0, 0);
         }
     };
-    const int nsteps = a.nchunks * 9;
-    auto dma_weights = [&](int s) {                    // step s = chunk * 9 + tap -> ring slot s % kStages
-        const int chunk = s / 9, tap = s - 9 * chunk;
-        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(2 * (tap * a.C + chunk * 64)));
+    const int nsteps = a.nchunks * 9 * SPT;
+    auto dma_weights = [&](int s) {                    // step s = (chunk * 9 + tap) * SPT + half -> ring slot s % kStages
+        const int ct = s / SPT, half = s - ct * SPT;
+        const int chunk = ct / 9, tap = ct - 9 * chunk;
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(2 * (tap * a.C + chunk * 64 + half * KS)));
         char* dst = wst + (s % kStages) * W_BYTES + wave * (W_PW * 1024);
 #pragma unroll
         for (int i = 0; i < W_PW; ++i)
@@ -119,16 +129,16 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
     int pc[FM];                                   // patch-local centre pixel of this lane's pixel, per fragment
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        int m = m0 + wave * WTM + i * 16 + fr;
+        int m = m0 + wm * WTM + i * 16 + fr;
         m = m < mend ? m : mend - 1;              // idle slots recompute the tile's last pixel; never stored
         pc[i] = (int)(centre(m) - P0);
     }
-    int wrd[FN][2];
+    int wrd[FN][KK];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const int row = j * 16 + fr;
+        const int row = wn * 64 + j * 16 + fr;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) wrd[j][kk] = row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+        for (int kk = 0; kk < KK; ++kk) wrd[j][kk] = row * RB + (((kk * 4 + fq) ^ wswz(row)) << 4);
     }
 
     f32x4 acc[FM][FN];
@@ -145,8 +155,10 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
     g.out_sn = a.out_sn; g.out_sd = 0; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
     g.res_sn = a.res_sn; g.res_sd = 0; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
     g.relu = a.relu; g.out_f32 = 0; g.res_f32 = 0;
-    EpiState<FM, FN> est;
-    epilogue_prepare<FM, FN>(est, g, m0 + wave * WTM, tn * BN, lane);
+    // (the 128-pixel wave tile has no registers to spare for that during the K loop and prepares afterwards)
+    constexpr bool kEarlyEpi = FM <= 4;
+    EpiState<(kEarlyEpi ? FM : 4), FN> est;
+    if constexpr (kEarlyEpi) epilogue_prepare<FM, FN>(est, g, m0 + wm * WTM, tn * BN + wn * 64, lane);
 
     // ---- prologue: patch of chunk 0, weights of steps 0 and 1 ----------------------------------
     // Waits are counted: vmcnt(W_PW) retires everything but the youngest weight stage, so one stage stays
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
 #if defined(ASL_STAMPS)
     st[1] = __builtin_amdgcn_s_memtime();
 #endif
-    int tap = 0, chunk = 0;
+    int tap = 0, chunk = 0, half = 0;
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
 #if !defined(ASL_ABL_NODMA)
@@ -172,28 +184,31 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
         const int r = tap / 3, q = tap - 3 * r;
         const int toff = (r - 1) * a.Wp + (q - 1);
         const char* wb = wst + (s % kStages) * W_BYTES;
+        bf16x8 xf[KK][FM], wf[KK][FN];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 xf[FM], wf[FN];
+        for (int kk = 0; kk < KK; ++kk) {
+            const int c16 = (half * KK + kk) * 4 + fq;          // 16-byte chunk of the pixel's 128-byte row
+#pragma unroll
+            for (int j = 0; j < FN; ++j) wf[kk][j] = *(const bf16x8*)(wb + wrd[j][kk]);
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int p = pc[i] + toff;
-                xf[i] = *(const bf16x8*)(smem + p * 128 + (((kk * 4 + fq) ^ ((p >> 1) & 7)) << 4));
+                xf[kk][i] = *(const bf16x8*)(smem + p * 128 + ((c16 ^ ((p >> 1) & 7)) << 4));
             }
+        }
+        // 4-wave shapes: all fragment reads issue before the first MFMA, so one LDS latency is exposed per
+        // step instead of one per fragment group (the 8-wave shape has no registers for that and would
+        // lose a resident wave per SIMD)
+        if constexpr (NW == 4) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(wb + wrd[j][kk]);
+        for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-#if defined(ASL_ABL_NOMFMA)
-                    asm volatile("" ::"v"(wf[j]), "v"(xf[i]));
-#else
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-#endif
-                }
-        }
-        if (++tap == 9) {
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][j], xf[kk][i], acc[i][j], 0, 0, 0);
+        if (++half == SPT) { half = 0; ++tap; }
+        if (tap == 9) {
             tap = 0;
             ++chunk;
             if (chunk < a.nchunks) {
@@ -205,8 +220,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
                 continue;
             }
         }
+#if defined(ASL_ABL_NOBAR)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(W_PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     }
 #if defined(ASL_ABL_NOEPI)
     if (a.M > 0) { if (acc[0][0][0] == 123.456f) a.y[0] = 1; return; }
@@ -217,7 +236,16 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
 
     // ---- epilogue: the staging LDS overlays the patch; the loop's last barrier frees it ------------
     static_assert(NW * kEpiWaveBytes(FN * 16) <= kPatchBytes, "epilogue stage does not fit the patch buffer");
-    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(FN * 16), g, est, lane);
+    char* const stage = smem + wave * kEpiWaveBytes(FN * 16);
+    if constexpr (kEarlyEpi) {
+        epilogue_store<FM, FN>(acc, stage, g, est, lane);
+    } else {
+#pragma unroll
+        for (int hf = 0; hf < FM / 4; ++hf) {
+            epilogue_prepare<4, FN>(est, g, m0 + wm * WTM + hf * 64, tn * BN + wn * 64, lane);
+            epilogue_store<4, FN>(*(const f32x4(*)[4][FN])&acc[hf * 4], stage, g, est, lane);
+        }
+    }
 #if defined(ASL_STAMPS)
     st[3] = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -269,7 +297,11 @@ int launch_conv3x3_patch(PatchArgs a, hipStream_t stream) {
         a.nchunks * 64 != a.C || a.Wp != a.W + 2 * a.in_halo || a.Hp != a.H + 2 * a.in_halo)
         return ASL_EINVAL;
     a.tiles_m = (a.M + a.bmv - 1) / a.bmv;
-    a.tiles_n = (a.N + 63) / 64;
+    // 128-channel tiles: a third fewer LDS fragment reads per MFMA and half the patch traffic
+    // (measured no faster than the 64-channel tile on any ResNet layer: both shapes run ~1.5x the MFMA-bound
+    // step time; the wide shape is kept selectable for experiments)
+    const bool wide = a.N > 64 && a.nchunks > 1 && getenv("ASL_PATCH_WIDE");
+    a.tiles_n = wide ? (a.N + 127) / 128 : (a.N + 63) / 64;
     // 100 MHz ticks: ~0.2 us per K step is half of a tile's measured duration; only worth it when the
     // grid runs for many rounds of 512 resident workgroups
     a.stagger_ticks = 0;
@@ -279,11 +311,14 @@ int launch_conv3x3_patch(PatchArgs a, hipStream_t stream) {
     if (const char* e2 = getenv("ASL_PATCH_LDS_PAD")) lds += atoi(e2);
     // single-chunk layers (C = 64) are prologue/epilogue-bound: 8 waves split that work finer
     const bool w8 = a.nchunks == 1 && !getenv("ASL_PATCH_4WAVES");
-    hipError_t e = hipFuncSetAttribute(w8 ? (const void*)conv3x3_patch_kernel<8> : (const void*)conv3x3_patch_kernel<4>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const void* fn = wide ? (const void*)conv3x3_patch_kernel<4, 128>
+                          : w8 ? (const void*)conv3x3_patch_kernel<8, 64> : (const void*)conv3x3_patch_kernel<4, 64>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    if (w8) hipLaunchKernelGGL(conv3x3_patch_kernel<8>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL(conv3x3_patch_kernel<4>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), lds, stream, a);
+    const dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+    if (wide) hipLaunchKernelGGL((conv3x3_patch_kernel<4, 128>), grid, dim3(256), lds, stream, a);
+    else if (w8) hipLaunchKernelGGL((conv3x3_patch_kernel<8, 64>), grid, dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<4, 64>), grid, dim3(256), lds, stream, a);
     return (int)hipGetLastError();
 }
 
