@@ -513,6 +513,11 @@ int main(int argc, char** argv) {
             {5, 7, 7, 256, 104, 1, 1, 0, 0, 0, false, false, true, 0, 0},
             {2, 6, 6, 64, 36, 1, 1, 0, 1, 1, false, true, true, 96, 32},
             {2, 6, 6, 160, 200, 3, 1, 1, 1, 1, false, true, true, 0, 0},
+            // large-tile 3x3 kernel: partial last tiles, tiles straddling rows and images, wide halo
+            {23, 14, 14, 128, 128, 3, 1, 1, 1, 1, true, true, true, 0, 0},
+            {3, 28, 28, 128, 256, 3, 1, 1, 1, 1, false, true, true, 0, 0},
+            {21, 7, 7, 256, 128, 3, 1, 1, 1, 0, true, false, true, 0, 0},
+            {2, 10, 10, 128, 128, 3, 1, 1, 2, 1, false, true, false, 0, 0},
         };
         for (const auto& c : cases) check_conv(c);
         check_stem(2, 32, 64, 1);

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
 #endif
 }
 
-namespace {
+// Largest patch (pixels, halo included) any tile of bmv consecutive output pixels needs
 long long max_patch_pixels(int n, int h, int w, int in_halo, int bmv) {
     const int hp = h + 2 * in_halo, wp = w + 2 * in_halo;
     const long long M = (long long)n * h * w, hw = (long long)h * w;
@@ -275,7 +275,6 @@ long long max_patch_pixels(int n, int h, int w, int in_halo, int bmv) {
     }
     return mx;
 }
-}  // namespace
 
 // Pixel slots per tile for this geometry (0 = the patch kernel cannot run it): 256 consecutive pixels
 // when their patch always fits; else whole images; else whole rows that tile an image exactly.

@@ -1,0 +1,298 @@
+// 3x3 / stride 1 / pad 1 convolution, large-tile "ping-pong" kernel for C >= 128 (gfx950).
+//
+// Same idea as conv3x3_patch.hip -- the halo'd input range of a run of consecutive output pixels sits
+// in LDS and all nine taps read it at constant offsets -- rebuilt around 8-wave workgroups:
+//
+//  * 8 waves as 4 (pixels) x 2 (channels); tile = 512 or 256 pixel slots x 128 output channels, every wave a
+//    128- or 64-pixel x 64-channel register tile;
+//  * K advances in steps of (32-channel half-chunk, tap): the patch of a half-chunk is 64 B per pixel,
+//    double-buffered, and the next half-chunk's patch streams in one LDS-DMA piece per step while the
+//    current one is consumed -- no reload bubble between chunks;
+//  * weight stages (tile channels x 32 k, 64-byte rows) run through a 3- or 4-deep LDS-DMA ring, two or
+//    three stages ahead of the reads, retired by counted s_waitcnt vmcnt so loads stay in flight
+//    across every barrier;
+//  * the two halves of the workgroup (waves 0-3 / 4-7, one of each per SIMD) run one phase apart:
+//    while one half issues its DMA pieces and fragment reads, the other half runs its MFMAs, and
+//    a raw s_barrier swaps the roles.
+//
+// MFMA orientation, epilogue and weight packing are those of gather_gemm.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "asl_hip.h"
+#include "common.h"
+#include "epilogue.h"
+#include "patch_args.h"
+
+namespace asl_detail {
+
+// Shape BIG: 512 pixels x 128 channels, 128-pixel wave tiles, 144 KiB of LDS -> one workgroup per CU.
+// Shape TWIN: 256 pixels x 128 channels, 64-pixel wave tiles, 80 KiB and <= 128 VGPRs -> two workgroups per
+// CU, each covering the other's prologue and epilogue.
+template <int FM_>
+struct PpShape {
+    static constexpr int WPX = 4, WCO = 2, FM = FM_;
+    static constexpr int TP = WPX * FM * 16;             // pixel slots per tile
+    static constexpr int TN = WCO * 64;                  // output channels per tile
+    static constexpr int PCAP = FM == 8 ? 896 : 448;     // patch buffer, pixels (64 B each)
+    static constexpr int PIECES = PCAP / 16;             // 1 KiB LDS-DMA pieces per half-chunk patch
+    static constexpr int PPW = (PIECES + 7) / 8;         // pieces per wave (<= 7: one per tap step)
+    // when PIECES is not a multiple of 8 the surplus pieces of the last round zero-fill the buffer's last
+    // piece, which therefore never holds live pixels
+    static constexpr int PLIVE = PIECES % 8 ? PCAP - 16 : PCAP;
+    static constexpr int PATCH_BYTES = PCAP * 64;
+    static constexpr int WST = TN * 64;                  // one weight stage: TN rows x 32 k
+    static constexpr int WPW = WST / 1024 / 8;           // weight DMA pieces per wave per stage
+    static constexpr int RING = FM == 8 ? 4 : 3;         // weight ring depth; prefetch distance RING - 1
+    static constexpr int LDS = 2 * PATCH_BYTES + RING * WST;
+    static constexpr int WAVES_PER_EU = FM == 8 ? 2 : 4;
+    static_assert(PPW >= 1 && PPW <= 7 && WPW >= 1, "piece counts");
+};
+
+template <int FM_>
+__global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_kernel(const PatchArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using S = PpShape<FM_>;
+    constexpr int WCO = S::WCO, FM = S::FM, FN = 4;
+    constexpr int PPW = S::PPW, WPW = S::WPW, WST = S::WST, RING = S::RING, DIST = RING - 1;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ring = smem + 2 * S::PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave / WCO, wc = wave % WCO;
+    const bool late = wave >= 4;                        // the half that runs one phase behind
+#if defined(ASL_STAMPS)
+    unsigned long long st[5];
+    st[0] = __builtin_amdgcn_s_memtime();
+#endif
+
+    int lbid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lbid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = lbid % a.tiles_n, tm = lbid / a.tiles_n;
+    const int m0 = tm * a.bmv;
+    const int HW = a.H * a.W;
+    auto centre = [&](int m) -> long long {             // halo'd, image-major pixel index of output pixel m
+        const int n = (int)fdiv(m, a.dOHW), r1 = m - n * HW;
+        const int y = (int)fdiv(r1, a.dOW), x = r1 - y * a.W;
+        return ((long long)n * a.Hp + y + a.in_halo) * a.Wp + x + a.in_halo;
+    };
+    const int mend = (m0 + a.bmv < a.M ? m0 + a.bmv : a.M);
+    const long long P0 = centre(m0) - a.Wp - 1;
+    const int NP = (int)(centre(mend - 1) + a.Wp + 1 - P0) + 1;       // <= PCAP (checked on the host)
+    const int nhc = a.C >> 5;                                         // 32-channel half-chunks
+    const int nsteps = nhc * 9;
+
+    // ---- DMA descriptors and per-lane source offsets ------------------------------------------
+    const long long pix_bytes = 2LL * a.C;
+    const char* xbase = a.x + P0 * pix_bytes;
+    long long xrem = a.x_bytes - P0 * pix_bytes;
+    const unsigned xrec = (unsigned)(xrem > 0x7fffffffLL ? 0x7fffffffLL : xrem);
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, xrec, 0x00020000);
+    const char* wbase = a.w + 2LL * (tn * S::TN) * a.wk;
+    const unsigned wrec = (unsigned)(a.w_bytes - 2LL * (tn * S::TN) * a.wk);
+    __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wrec, 0x00020000);
+    constexpr unsigned kOob = 0x80000000u;              // beyond num_records: the DMA writes zeros
+
+    // patch piece j covers patch pixels 16j..16j+15 (64 B each): lane -> pixel 16j + lane/4, slot lane%4,
+    // which holds 16-byte chunk (lane%4) ^ swz(p), swz(p) = (p & 4) >> 1 (conflict-free fragment reads
+    // from any 16 consecutive pixels)
+    const unsigned pvoff = (unsigned)((lane >> 2) * pix_bytes + 16 * ((lane & 3) ^ ((lane >> 3) & 2)));
+    auto dma_patch_piece = [&](int hc, int k) {         // piece (wave + 8k) of half-chunk hc
+        const int j = wave + 8 * k;
+        const bool live = hc < nhc && 16 * j < NP;      // else: zeros, into the piece itself or the spare last piece
+        const int jd = j < S::PIECES ? j : S::PIECES - 1;
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(16LL * j * pix_bytes + hc * 64));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(smem + (hc & 1) * S::PATCH_BYTES + jd * 1024),
+                                                 16, live ? pvoff : kOob, live ? so : 0u, 0, 0);
+    };
+    // weight piece q = wave * WPW + i covers tile rows 16q..16q+15 (64 B each); chunk swizzle (row & 8) ? 3 : 0
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int row = (wave * WPW + i) * 16 + (lane >> 2);
+        wvoff[i] = (unsigned)(2 * row * a.wk + 16 * ((lane & 3) ^ ((row & 8) ? 3 : 0)));
+    }
+    auto dma_weights = [&](int s, int slot) {           // stage s = hc * 9 + tap -> ring slot s % RING
+        const bool live = s < nsteps;
+        const int hc = s / 9, tap = s - 9 * hc;
+        const unsigned so = __builtin_amdgcn_readfirstlane(live ? (unsigned)(2 * (tap * a.C + hc * 32)) : 0u);
+        char* dst = ring + slot * WST + wave * (WPW * 1024);
+#pragma unroll
+        for (int i = 0; i < WPW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                                     live ? wvoff[i] : kOob, so, 0, 0);
+    };
+
+    // ---- per-lane fragment geometry ----------------------------------------------------------
+    const int fr = lane & 15, fq = lane >> 4;
+    int pc[FM];                                         // byte offset of (centre pixel, chunk fq) in an unswizzled patch
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        int m = m0 + wp * (FM * 16) + i * 16 + fr;
+        m = m < mend ? m : mend - 1;                    // idle slots recompute the tile's last pixel; never stored
+        pc[i] = (int)(centre(m) - P0) * 64 + fq * 16;
+    }
+    int wrd[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int row = wc * 64 + j * 16 + fr;
+        wrd[j] = row * 64 + ((fq ^ ((row & 8) ? 3 : 0)) << 4);
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: patch of half-chunk 0, weight stages 0..2 ------------------------------------
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) dma_patch_piece(0, k);
+#pragma unroll
+    for (int d = 0; d < DIST; ++d) dma_weights(d, d);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DIST - 1) * WPW) : "memory");   // patch 0 and stage 0 landed
+    if (late) asm volatile("s_barrier" ::: "memory");                                 // run one phase behind
+#if defined(ASL_STAMPS)
+    st[1] = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- K loop ---------------------------------------------------------------------------------
+    // Step s: load phase L(s) = {DMA pieces of stage s+3 and of the next half-chunk's patch, the 12 fragment
+    // reads of step s, counted wait retiring stage s+1} | barrier | compute phase = 32 MFMAs | barrier.
+    // The wait leaves the pieces issued in L(s-1) and L(s) in flight: I(t) = WPW + (t < PPW) pieces in L of tap t.
+    int hc = 0;
+    const char* pbuf = smem;
+    auto step = [&](auto tapc) {
+        constexpr int tap = decltype(tapc)::value;
+        const int s = hc * 9 + tap;
+        // ring slot of step s: 9 = 0 (mod 3) and 9 = 1 (mod 4)
+        const int slot = RING == 3 ? tap % 3 : ((hc + tap) & 3);
+        const int slot_next = RING == 3 ? (tap + DIST) % 3 : ((hc + tap + DIST) & 3);
+        if constexpr (tap < PPW) dma_patch_piece(hc + 1, tap);
+        dma_weights(s + DIST, slot_next);
+        const int toff = ((tap / 3 - 1) * a.Wp + (tap % 3 - 1)) * 64;
+        const char* wb = ring + slot * WST;
+        bf16x8 xf[FM], wf[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(wb + wrd[j]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            // byte offset t = 64 p + 16 fq; the chunk swizzle (p & 4) >> 1 is bit 8 of t moved to bit 5.
+            // The empty asm keeps the compiler from hoisting 72 tap addresses out of the K loop into VGPRs.
+            int t = pc[i];
+            asm volatile("" : "+v"(t));
+            t += toff;
+            xf[i] = *(const bf16x8*)(pbuf + (t ^ ((t >> 3) & 0x20)));
+        }
+        // pieces that may stay in flight: those of the last DIST - 1 load phases, this one included
+        constexpr int kPrev = tap == 0 ? 8 : tap - 1;
+        constexpr int kInFlight = (DIST == 3 ? (WPW + (kPrev < PPW ? 1 : 0)) : 0) + (WPW + (tap < PPW ? 1 : 0));
+        static_assert(DIST == 2 || DIST == 3, "wait counts are written for prefetch distance 2 or 3");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kInFlight) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+    };
+#pragma unroll 1
+    for (hc = 0; hc < nhc; ++hc) {
+        pbuf = smem + (hc & 1) * S::PATCH_BYTES;
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
+    }
+    if (!late) asm volatile("s_barrier" ::: "memory");  // the early half waits out the late half's last phase
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // trailing zero-fill pieces have landed
+#if defined(ASL_STAMPS)
+    st[2] = __builtin_amdgcn_s_memtime();
+#endif
+
+    // ---- epilogue: wave-private staging overlays the patch buffers ----------------------------------
+    OutGeom g;
+    g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = mend; g.N = a.N;
+    g.dOW = a.dOW; g.dOHW = a.dOHW; g.dODHW = a.dODHW;
+    g.out_sn = a.out_sn; g.out_sd = 0; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
+    g.res_sn = a.res_sn; g.res_sd = 0; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
+    g.relu = a.relu; g.out_f32 = 0; g.res_f32 = 0;
+    static_assert(8 * kEpiWaveBytes(64) <= 2 * S::PATCH_BYTES, "epilogue stage does not fit the patch buffers");
+    char* const stage = smem + wave * kEpiWaveBytes(64);
+    constexpr int EF = FM == 8 ? 4 : 2;                 // pixel fragments per epilogue pass (registers)
+    EpiState<EF, FN> est;
+#pragma unroll
+    for (int hf = 0; hf < FM / EF; ++hf) {
+        epilogue_prepare<EF, FN>(est, g, m0 + wp * (FM * 16) + hf * (EF * 16), tn * S::TN + wc * 64, lane);
+        epilogue_store<EF, FN>(*(const f32x4(*)[EF][FN])&acc[hf * EF], stage, g, est, lane);
+    }
+#if defined(ASL_STAMPS)
+    st[3] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[4] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && tid == 0)
+        for (int k = 0; k < 5; ++k) a.stamps[(long long)blockIdx.x * 5 + k] = st[k];
+#endif
+#endif
+}
+
+// pixel slots per tile for this geometry (0 = it does not fit the shape): a full tile of consecutive
+// pixels when its patch always fits, else whole images
+template <int FM_>
+static int pp_tile(int n, int h, int w, int in_halo) {
+    using S = PpShape<FM_>;
+    if (max_patch_pixels(n, h, w, in_halo, S::TP) <= S::PLIVE) return S::TP;
+    const int hw = h * w;
+    if (hw <= S::TP) {
+        const int b = S::TP / hw * hw;
+        if (b * 8 >= S::TP * 7 && max_patch_pixels(n, h, w, in_halo, b) <= S::PLIVE) return b;
+    }
+    return 0;
+}
+
+template <int FM_>
+static int pp_launch(PatchArgs a, hipStream_t stream) {
+    using S = PpShape<FM_>;
+    a.tiles_m = (a.M + a.bmv - 1) / a.bmv;
+    a.tiles_n = (a.N + S::TN - 1) / S::TN;
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_pp_kernel<FM_>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((conv3x3_pp_kernel<FM_>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), S::LDS, stream, a);
+    return (int)hipGetLastError();
+}
+
+// Runs the request on the large-tile kernel when it fits: C a multiple of 32 and at least 128, N a multiple
+// of 128.  Returns -1 when it does not apply (the caller falls back).
+int try_launch_conv3x3_pp(PatchArgs a, int n, hipStream_t stream) {
+    if (a.C % 32 || a.C < 128 || a.N % 128 || getenv("ASL_NO_PP_CONV")) return -1;
+    if (a.W <= 0 || a.H <= 0 || (int)a.dOW.d != a.W || (int)a.dOHW.d != a.H * a.W || a.Wp != a.W + 2 * a.in_halo ||
+        a.Hp != a.H + 2 * a.in_halo)
+        return -1;
+    if (!getenv("ASL_PP_BIG")) {
+        a.bmv = pp_tile<4>(n, a.H, a.W, a.in_halo);
+        if (a.bmv) return pp_launch<4>(a, stream);
+    }
+    a.bmv = pp_tile<8>(n, a.H, a.W, a.in_halo);
+    if (a.bmv) return pp_launch<8>(a, stream);
+    return -1;
+}
+
+}  // namespace asl_detail

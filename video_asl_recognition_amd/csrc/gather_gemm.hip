@@ -302,13 +302,12 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
         p->in.sn % p->tap_sh == 0 && !getenv("ASL_NO_PATCH_CONV")) {
         const int C = p->ck, Wp = p->tap_sh / C, Hp = (int)(p->in.sn / p->tap_sh);
         const int halo = (Wp - p->ow) / 2;
-        int bmv = 0;
         if (halo >= 1 && Wp == p->ow + 2 * halo && Hp == p->oh + 2 * halo &&
-            p->in.off0 == ((halo - 1) * Wp + (halo - 1)) * C && (bmv = patch_conv_tile(p->nb, p->oh, p->ow, halo)) > 0) {
+            p->in.off0 == ((halo - 1) * Wp + (halo - 1)) * C) {
             PatchArgs b = {};
             b.x = a.x; b.w = a.w; b.scale = a.scale; b.bias = a.bias; b.res = a.res; b.y = a.y;
             b.M = a.M; b.N = a.N; b.H = p->oh; b.W = p->ow; b.Hp = Hp; b.Wp = Wp; b.in_halo = halo;
-            b.C = C; b.nchunks = C / 64; b.bmv = bmv; b.wk = a.wk; b.x_bytes = a.x_bytes; b.w_bytes = a.w_bytes;
+            b.C = C; b.nchunks = C / 64; b.bmv = 0; b.wk = a.wk; b.x_bytes = a.x_bytes; b.w_bytes = a.w_bytes;
             b.out_sn = a.out_sn; b.out_sh = a.out_sh; b.out_sw = a.out_sw; b.out_off0 = a.out_off0;
             b.res_sn = a.res_sn; b.res_sh = a.res_sh; b.res_sw = a.res_sw; b.res_off0 = a.res_off0;
             b.relu = a.relu; b.tiles_m = b.tiles_n = 0; b.stamps = nullptr;
@@ -316,7 +315,9 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
             if (const char* e = getenv("ASL_STAMP_PTR")) b.stamps = (unsigned long long*)strtoull(e, nullptr, 16);
 #endif
             b.dOW = a.dOW; b.dOHW = a.dOHW; b.dODHW = a.dODHW;
-            return launch_conv3x3_patch(b, s);
+            const int r = try_launch_conv3x3_pp(b, p->nb, s);      // C >= 128: one 8-wave workgroup per CU
+            if (r >= 0) return r;
+            if ((b.bmv = patch_conv_tile(p->nb, p->oh, p->ow, halo)) > 0) return launch_conv3x3_patch(b, s);
         }
     }
     if (p->ck % 64 == 0) {
