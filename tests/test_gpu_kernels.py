@@ -51,6 +51,12 @@ CONV_CASES = [
     (2, 9, 13, 32, 64, 3, 2, 1, False, True),
     (2, 14, 14, 256, 1024, 1, 1, 0, True, True),
     (1, 1, 1, 64, 64, 1, 1, 0, False, False),
+    # more tiles than CUs: the persistent 64->64 kernel walks several tiles per workgroup through both patch buffers
+    (260, 56, 56, 64, 64, 3, 1, 1, True, True),
+    # 8-wave large-tile kernel: tiles straddling rows and images, partial last tile, several channel tiles
+    (9, 28, 28, 128, 128, 3, 1, 1, True, True),
+    (40, 14, 14, 256, 256, 3, 1, 1, True, True),
+    (30, 7, 7, 512, 512, 3, 1, 1, False, True),
 ]
 
 
@@ -81,6 +87,11 @@ def test_conv2d_bn_res_relu(gpu, n, h, w, cin, cout, k, stride, pad, res, relu):
     torch.cuda.synchronize()
     assert yd[:, 0].abs().sum() == 0 and yd[:, :, 0].abs().sum() == 0, "halo was written"
     _assert_bf16_close(_unhalo(yd, 1), ref)
+    # a second launch must reproduce the first bit for bit (a data race shows up as run-to-run variation)
+    y1 = yd.clone()
+    L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(p), _p(xd), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(rd), _p(yd), None))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, yd), "two launches on the same input differ"
 
 
 def test_stem_conv_and_pack_clips(gpu):

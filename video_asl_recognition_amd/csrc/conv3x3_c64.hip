@@ -8,7 +8,7 @@
 // residual values are already in registers when the K loop ends, and the K loop itself has no
 // barrier and no wait on global memory.  Per tile: one barrier.
 //
-// LDS: weights 9 x 64 x 128 B = 73,728 + two patches of 348 pixels x 128 B = 89,088 -> 162,816 B.
+// LDS: weights 9 x 64 x 128 B = 73,728 + two patches of 352 pixels x 128 B = 90,112 -> 163,840 B (all of it).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -19,7 +19,8 @@
 
 namespace asl_detail {
 
-constexpr int kC64PatchPixels = 348;
+constexpr int kC64PatchPixels = 352;             // whole 8-pixel DMA pieces: a piece must not spill into the other buffer
+static_assert(kC64PatchPixels % 8 == 0, "patch buffers hold whole DMA pieces");
 constexpr int kC64PatchBytes = kC64PatchPixels * 128;
 constexpr int kC64WeightBytes = 9 * 64 * 128;
 constexpr int kC64Lds = kC64WeightBytes + 2 * kC64PatchBytes;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const PatchArgs a) {
 #endif
 }
 
-// pixel slots per tile for the 348-pixel patch buffers (0 = geometry does not fit)
+// pixel slots per tile for the patch buffers (0 = geometry does not fit)
 static int c64_tile(int n, int h, int w, int in_halo) {
     if (max_patch_pixels(n, h, w, in_halo, 256) <= kC64PatchPixels) return 256;
     const int hw = h * w;
