@@ -113,6 +113,7 @@ def main():
         flops_step = conv_flops_per_frame(model) * B * T
         assert conv_flops_per_frame(model) == 2 * R18_CONV_MAC_PER_FRAME
         achieved = flops_step / (conv_ms * 1e-3) / 1e12
+        traffic, traffic_note = pmc_traffic_per_launch()
         result = {
             "metric": "clips/sec end-to-end (T=64, 224x224, bf16)",
             "value": round(clips_per_s, 2),
@@ -132,12 +133,14 @@ def main():
                        "parallelism": f"batch-sharded x{world}, all-gather of logits"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv MFMA kernels (gather_gemm_kernel + conv3x3_patch_kernel), all conv launches of one step",
+                "kernel": "conv MFMA kernels (stem_pool_kernel, conv3x3_c64_kernel, conv3x3_pp_kernel, gather_gemm_kernel), "
+                          "all conv launches of one step",
                 "achieved": round(achieved, 2),
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "launches_per_step": launches,
                 "avg_launch_us": round(conv_ms * 1e3 / launches, 2),
                 "algorithmic_gflop_per_step": round(flops_step / 1e9, 1),
@@ -150,6 +153,28 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+CONV_KERNELS = ("stem_pool_kernel", "conv3x3_c64_kernel", "conv3x3_pp_kernel", "conv3x3_patch_kernel", "gather_gemm_kernel")
+
+
+def pmc_traffic_per_launch(path=os.path.join(ROOT, "profiles", "r01_final_pmc_summary.csv")):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC summary of this same command
+    ((2 * FETCH_SIZE + WRITE_SIZE) KiB per kernel, separate --pmc passes): counters cannot be read from
+    inside the timed run, so the figure is the last profiled one, or None when no summary is present."""
+    try:
+        tot, n = 0.0, 0
+        with open(path) as f:
+            for line in f:
+                parts = line.rstrip("\n").rsplit(",", 4)
+                if len(parts) == 5 and parts[1] == "HBM_BYTES_corrected" and any(k in parts[0] for k in CONV_KERNELS):
+                    tot += float(parts[3])
+                    n += int(parts[2])
+        if n:
+            return round(tot / n), f"HBM bytes per launch averaged over {n} profiled conv launches ({os.path.basename(path)})"
+    except OSError:
+        pass
+    return None, "no PMC summary found"
 
 
 def time_conv_launches(model, clips, passes=3):
