@@ -253,18 +253,26 @@ class AslClipModel:
         side = self._side_streams(nstreams)
         for s_ in side:
             s_.wait_stream(main)
-        for k, c0 in enumerate(range(0, n_total, step)):
-            plan = plans[k % nstreams]
-            st = main if nstreams == 1 else side[k % nstreams]
-            stream = C.c_void_p(st.cuda_stream)
-            n = min(step, n_total - c0)
-            fill_x0(c0, n, plan["x0"], plan["in_halo"], stream)
-            for op in plan["ops"]:
-                op(n, stream)
-            last: Act = plan["last"]
-            fb = None if feats_b is None else C.c_void_p(feats_b.data_ptr() + c0 * ld_b * 2)
-            L.check(L.lib.asl_avgpool_nhwc(_ptr(last.t), n, last.h, last.w, last.c, last.halo,
-                                           C.c_void_p(feats.data_ptr() + c0 * F * 4), fb, ld_b, lo_off, stream), "avgpool")
+        # Chunks are issued in groups of `nstreams`, op by op across the group: the host needs ~15 us per
+        # launch, so issuing one chunk's ~23 launches before the next chunk's first would start the second
+        # stream more than 0.3 ms late and leave it running alone at the end.
+        starts = list(range(0, n_total, step))
+        for g0 in range(0, len(starts), nstreams):
+            group = []
+            for k in range(g0, min(g0 + nstreams, len(starts))):
+                plan = plans[k % nstreams]
+                st = main if nstreams == 1 else side[k % nstreams]
+                group.append((plan, C.c_void_p(st.cuda_stream), starts[k], min(step, n_total - starts[k])))
+            for plan, stream, c0, n in group:
+                fill_x0(c0, n, plan["x0"], plan["in_halo"], stream)
+            for i in range(len(group[0][0]["ops"])):
+                for plan, stream, c0, n in group:
+                    plan["ops"][i](n, stream)
+            for plan, stream, c0, n in group:
+                last: Act = plan["last"]
+                fb = None if feats_b is None else C.c_void_p(feats_b.data_ptr() + c0 * ld_b * 2)
+                L.check(L.lib.asl_avgpool_nhwc(_ptr(last.t), n, last.h, last.w, last.c, last.halo,
+                                               C.c_void_p(feats.data_ptr() + c0 * F * 4), fb, ld_b, lo_off, stream), "avgpool")
         if nstreams > 1:
             for s_ in side:
                 main.wait_stream(s_)
