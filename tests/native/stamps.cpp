@@ -6,7 +6,7 @@
 #include <algorithm>
 #include "asl_hip.h"
 int main(int argc, char** argv) {
-    const int frames = 512, hw = argc > 1 ? atoi(argv[1]) : 56, c = argc > 2 ? atoi(argv[2]) : 64;
+    const int frames = argc > 3 ? atoi(argv[3]) : 512, hw = argc > 1 ? atoi(argv[1]) : 56, c = argc > 2 ? atoi(argv[2]) : 64;
     const int hp = hw + 2;
     size_t xe = (size_t)frames * hp * hp * c, we = (size_t)((c + 127) / 128 * 128) * 9 * c;
     void *x, *y, *r, *w; unsigned long long* st;

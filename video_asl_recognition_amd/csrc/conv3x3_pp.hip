@@ -169,11 +169,17 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
     // Step s: load phase L(s) = {DMA pieces of stage s+3 and of the next half-chunk's patch, the 12 fragment
     // reads of step s, counted wait retiring stage s+1} | barrier | compute phase = 32 MFMAs | barrier.
     // The wait leaves the pieces issued in L(s-1) and L(s) in flight: I(t) = WPW + (t < PPW) pieces in L of tap t.
+#if defined(ASL_STAMPS_PHASES)
+    unsigned long long ph[4] = {0, 0, 0, 0};   // diagnostic: issue (DMA + reads), wait + barrier, MFMA issue, second barrier
+#endif
     int hc = 0;
     const char* pbuf = smem;
     auto step = [&](auto tapc) {
         constexpr int tap = decltype(tapc)::value;
         const int s = hc * 9 + tap;
+#if defined(ASL_STAMPS_PHASES)
+        const unsigned long long tA = __builtin_amdgcn_s_memtime();
+#endif
         // ring slot of step s: 9 = 0 (mod 3) and 9 = 1 (mod 4)
         const int slot = RING == 3 ? tap % 3 : ((hc + tap) & 3);
         const int slot_next = RING == 3 ? (tap + DIST) % 3 : ((hc + tap + DIST) & 3);
@@ -197,7 +203,13 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         constexpr int kPrev = tap == 0 ? 8 : tap - 1;
         constexpr int kInFlight = (DIST == 3 ? (WPW + (kPrev < PPW ? 1 : 0)) : 0) + (WPW + (tap < PPW ? 1 : 0));
         static_assert(DIST == 2 || DIST == 3, "wait counts are written for prefetch distance 2 or 3");
+#if defined(ASL_STAMPS_PHASES)
+        const unsigned long long tB = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kInFlight) : "memory");
+#if defined(ASL_STAMPS_PHASES)
+        const unsigned long long tC = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -207,7 +219,14 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+#if defined(ASL_STAMPS_PHASES)
+        const unsigned long long tD = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_barrier" ::: "memory");
+#if defined(ASL_STAMPS_PHASES)
+        const unsigned long long tE = __builtin_amdgcn_s_memtime();
+        ph[0] += tB - tA; ph[1] += tC - tB; ph[2] += tD - tC; ph[3] += tE - tD;
+#endif
     };
 #pragma unroll 1
     for (hc = 0; hc < nhc; ++hc) {
@@ -248,8 +267,15 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
     st[3] = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st[4] = __builtin_amdgcn_s_memtime();
+#if defined(ASL_STAMPS_PHASES)
+    if (a.stamps && tid == 0) {
+        unsigned long long* o = a.stamps + (long long)blockIdx.x * 5;
+        o[0] = 1; o[1] = 1 + ph[0]; o[2] = o[1] + ph[1]; o[3] = o[2] + ph[2]; o[4] = o[3] + ph[3];
+    }
+#else
     if (a.stamps && tid == 0)
         for (int k = 0; k < 5; ++k) a.stamps[(long long)blockIdx.x * 5 + k] = st[k];
+#endif
 #endif
 #endif
 }

@@ -308,6 +308,7 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
             b.x = a.x; b.w = a.w; b.scale = a.scale; b.bias = a.bias; b.res = a.res; b.y = a.y;
             b.M = a.M; b.N = a.N; b.H = p->oh; b.W = p->ow; b.Hp = Hp; b.Wp = Wp; b.in_halo = halo;
             b.C = C; b.nchunks = C / 64; b.bmv = 0; b.wk = a.wk; b.x_bytes = a.x_bytes; b.w_bytes = a.w_bytes;
+            b.y_bytes = 2 * p->y_elems; b.res_bytes = res ? 2 * p->res_elems : 0;
             b.out_sn = a.out_sn; b.out_sh = a.out_sh; b.out_sw = a.out_sw; b.out_off0 = a.out_off0;
             b.res_sn = a.res_sn; b.res_sh = a.res_sh; b.res_sw = a.res_sw; b.res_off0 = a.res_off0;
             b.relu = a.relu; b.tiles_m = b.tiles_n = 0; b.stamps = nullptr;

@@ -21,6 +21,7 @@ struct PatchArgs {
     int bmv;               // valid pixel slots per 256-slot tile
     int wk;                // packed K per weight row (9*C)
     long long x_bytes, w_bytes;
+    long long y_bytes, res_bytes;   // extents of the output / residual tensors (kernels that address them by buffer descriptor)
     long long out_sn, res_sn;
     int out_sh, out_sw, out_off0;
     int res_sh, res_sw, res_off0;
