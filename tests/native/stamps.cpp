@@ -14,6 +14,7 @@ int main(int argc, char** argv) {
     hipMemset(x, 0, xe * 2); hipMemset(r, 0, xe * 2); hipMemset(w, 0, we * 2); hipMemset(y, 0, xe * 2);
     const size_t nst = 200000; hipMalloc(&st, nst * 5 * 8); hipMemset(st, 0, nst * 5 * 8);
     char buf[64]; snprintf(buf, sizeof buf, "%llx", (unsigned long long)st); setenv("ASL_STAMP_PTR", buf, 1);
+    if (getenv("ASL_STAMP_NORES")) r = nullptr;
     asl_conv2d_params p = {};
     p.n = frames; p.h = p.w = hw; p.cin = c; p.in_halo = 1; p.cout = c; p.kh = p.kw = 3; p.stride = 1; p.pad = 1;
     p.out_halo = 1; p.out_ctot = c; p.res_halo = 1; p.res_ctot = c; p.relu = 1; p.w_rows = (c + 127) / 128 * 128;

@@ -15,7 +15,7 @@
 //    while one half issues its DMA pieces and fragment reads, the other half runs its MFMAs, and
 //    a raw s_barrier swaps the roles.
 //
-// MFMA orientation, epilogue and weight packing are those of gather_gemm.hip.
+// MFMA orientation and weight packing are those of gather_gemm.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -24,7 +24,6 @@
 
 #include "asl_hip.h"
 #include "common.h"
-#include "epilogue.h"
 #include "patch_args.h"
 
 namespace asl_detail {
@@ -141,10 +140,14 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         m = m < mend ? m : mend - 1;                    // idle slots recompute the tile's last pixel; never stored
         pc[i] = (int)(centre(m) - P0) * 64 + fq * 16;
     }
+    // Weight rows are read in a permuted order so that a lane's accumulators for channel fragments 2h and
+    // 2h+1 are eight CONSECUTIVE output channels of its pixel (MFMA row r of fragment j is channel
+    // (j>>1)*32 + (r>>2)*8 + (j&1)*4 + (r&3) of the wave's 64): the epilogue stores 16 bytes per lane straight
+    // from registers.  The 64-byte-row swizzle is conflict-free for this order too.
     int wrd[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const int row = wc * 64 + j * 16 + fr;
+        const int row = wc * 64 + (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);
         wrd[j] = row * 64 + ((fq ^ ((row & 8) ? 3 : 0)) << 4);
     }
 
@@ -242,26 +245,64 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         step(std::integral_constant<int, 8>{});
     }
     if (!late) asm volatile("s_barrier" ::: "memory");  // the early half waits out the late half's last phase
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // trailing zero-fill pieces have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing zero-fill pieces have landed
 #if defined(ASL_STAMPS)
     st[2] = __builtin_amdgcn_s_memtime();
 #endif
 
-    // ---- epilogue: wave-private staging overlays the patch buffers ----------------------------------
-    OutGeom g;
-    g.scale = a.scale; g.bias = a.bias; g.res = a.res; g.y = a.y; g.M = mend; g.N = a.N;
-    g.dOW = a.dOW; g.dOHW = a.dOHW; g.dODHW = a.dODHW;
-    g.out_sn = a.out_sn; g.out_sd = 0; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
-    g.res_sn = a.res_sn; g.res_sd = 0; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
-    g.relu = a.relu; g.out_f32 = 0; g.res_f32 = 0;
-    static_assert(8 * kEpiWaveBytes(64) <= 2 * S::PATCH_BYTES, "epilogue stage does not fit the patch buffers");
-    char* const stage = smem + wave * kEpiWaveBytes(64);
-    constexpr int EF = FM == 8 ? 4 : 2;                 // pixel fragments per epilogue pass (registers)
-    EpiState<EF, FN> est;
+    // ---- epilogue, straight from registers: per 32-channel half, the residual loads of all pixel fragments
+    // are issued first, then scale/bias, residual, ReLU and one 16-byte store per (fragment, half).  Output
+    // and residual are addressed through buffer descriptors: masked lanes use an out-of-range offset
+    // (stores dropped, loads return 0), so nothing branches.  The host guarantees both are under 4 GiB.
+    {
+        constexpr unsigned kOobOff = 0xffffffffu;
+        __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (unsigned)a.y_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.y), 0,
+                                                                       a.res ? (unsigned)a.res_bytes : 0u, 0x00020000);
+        const float floor_v = a.relu ? 0.f : -__builtin_inff();
+        const int ch0 = tn * S::TN + wc * 64 + fq * 8;   // first of this lane's 8 channels in half 0
+        unsigned oe[FM], re[FM];
 #pragma unroll
-    for (int hf = 0; hf < FM / EF; ++hf) {
-        epilogue_prepare<EF, FN>(est, g, m0 + wp * (FM * 16) + hf * (EF * 16), tn * S::TN + wc * 64, lane);
-        epilogue_store<EF, FN>(*(const f32x4(*)[EF][FN])&acc[hf * EF], stage, g, est, lane);
+        for (int i = 0; i < FM; ++i) {
+            int m = m0 + wp * (FM * 16) + i * 16 + fr;
+            const bool ok = m < mend;
+            m = ok ? m : mend - 1;
+            const int n = (int)fdiv(m, a.dOHW), r1 = m - n * HW;
+            const int y = (int)fdiv(r1, a.dOW), x = r1 - y * a.W;
+            const long long o = (long long)n * a.out_sn + (long long)y * a.out_sh + (long long)x * a.out_sw + a.out_off0 + ch0;
+            const long long r = (long long)n * a.res_sn + (long long)y * a.res_sh + (long long)x * a.res_sw + a.res_off0 + ch0;
+            oe[i] = ok ? (unsigned)(2 * o) : kOobOff;
+            re[i] = ok ? (unsigned)(2 * r) : kOobOff;
+        }
+        // (FM = 4: all eight loads fit the registers the fragments have just vacated, one exposed latency)
+        constexpr int HB = FM <= 4 ? 2 : 1;              // halves whose residual loads are batched
+        i32x4 rv[HB][FM];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h % HB == 0) {
+#pragma unroll
+                for (int hh = 0; hh < HB; ++hh)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+                        rv[hh][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, re[i] == kOobOff ? kOobOff : re[i] + (h + hh) * 64, 0, 0);
+            }
+            f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, bi0 = {0.f, 0.f, 0.f, 0.f}, bi1 = bi0;
+            if (a.scale) { sc0 = *(const f32x4*)(a.scale + ch0 + h * 32); sc1 = *(const f32x4*)(a.scale + ch0 + h * 32 + 4); }
+            if (a.bias) { bi0 = *(const f32x4*)(a.bias + ch0 + h * 32); bi1 = *(const f32x4*)(a.bias + ch0 + h * 32 + 4); }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const f32x4 v0 = acc[i][2 * h] * sc0 + bi0;
+                const f32x4 v1 = acc[i][2 * h + 1] * sc1 + bi1;
+                const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[h % HB][i]);
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ov[e] = f32_to_bf16(fmaxf(v0[e] + bf16_to_f32(r8[e]), floor_v));
+                    ov[4 + e] = f32_to_bf16(fmaxf(v1[e] + bf16_to_f32(r8[4 + e]), floor_v));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ov), yrs, oe[i] == kOobOff ? kOobOff : oe[i] + h * 64, 0, 0);
+            }
+        }
     }
 #if defined(ASL_STAMPS)
     st[3] = __builtin_amdgcn_s_memtime();
@@ -309,6 +350,7 @@ static int pp_launch(PatchArgs a, hipStream_t stream) {
 // of 128.  Returns -1 when it does not apply (the caller falls back).
 int try_launch_conv3x3_pp(PatchArgs a, int n, hipStream_t stream) {
     if (a.C % 32 || a.C < 128 || a.N % 128 || getenv("ASL_NO_PP_CONV")) return -1;
+    if (a.y_bytes <= 0 || a.y_bytes >= 0xffffffffLL || (a.res && (a.res_bytes <= 0 || a.res_bytes >= 0xffffffffLL))) return -1;
     if (a.W <= 0 || a.H <= 0 || (int)a.dOW.d != a.W || (int)a.dOHW.d != a.H * a.W || a.Wp != a.W + 2 * a.in_halo ||
         a.Hp != a.H + 2 * a.in_halo)
         return -1;
