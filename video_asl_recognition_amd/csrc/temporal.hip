@@ -16,11 +16,12 @@ __device__ __forceinline__ float tanhf_(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// One time step of one bidirectional LSTM layer, both directions.  Thread = (direction, hidden
-// unit j, batch row b): four 512-long fp32 dot products h_prev[b] . W_hh[gate*H + j] (weights
-// bf16, read 8 at a time; neighbouring lanes share the weight rows), then the fused gate math
-// and state update.  h is kept in fp32 for the recurrence; the bf16 copy written to y feeds the
-// next layer's input GEMM.
+// One time step of one bidirectional LSTM layer, both directions.  Wave = (direction, hidden unit j):
+// its 64 lanes split the K axis of the four gate rows W_hh[gate*H + j] (bf16, 16 bytes per lane, read
+// once) against h_prev of up to four batch rows at a time (fp32), the partial sums are reduced across
+// the wave, and lanes 0..3 finish one batch row each: fused gate math and state update.  A step is a
+// single round of coalesced loads instead of a 64-deep dependent chain per thread.  h is kept in fp32
+// for the recurrence; the bf16 copy written to y feeds the next layer's input GEMM.
 // ---------------------------------------------------------------------------------------------
 struct LstmArgs {
     const float* gx;       // [B*T][ld_gx] fp32: x W_ih^T + b_ih + b_hh, forward gates then reverse gates
@@ -35,43 +36,66 @@ struct LstmArgs {
 };
 
 __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a) {
-    const int per_dir = a.H * a.B;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= 2 * per_dir) return;
-    const int d = idx / per_dir, rem = idx - d * per_dir;
-    const int j = rem / a.B, b = rem - j * a.B;
-    const int t = d == 0 ? a.step : a.T - 1 - a.step;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);          // (direction, unit)
     const int H = a.H;
-    const float* hp = a.h_prev + ((long long)d * a.B + b) * H;
+    if (wid >= 2 * H) return;
+    const int d = wid / H, j = wid - d * H;
+    const int t = d == 0 ? a.step : a.T - 1 - a.step;
     const short* w = a.whh + (long long)d * 4 * H * H + (long long)j * H;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < H; k += 8) {
-        const f32x4 h0 = *(const f32x4*)(hp + k), h1 = *(const f32x4*)(hp + k + 4);
+    for (int b0 = 0; b0 < a.B; b0 += 4) {
+        const int nb = a.B - b0 < 4 ? a.B - b0 : 4;
+        float acc[4][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const bf16x8 wv = *(const bf16x8*)(w + (long long)g * H * H + k);
+        for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[g] = fmaf(h0[e], bf16_to_f32(wv[e]), acc[g]);
-                acc[g] = fmaf(h1[e], bf16_to_f32(wv[4 + e]), acc[g]);
+            for (int g = 0; g < 4; ++g) acc[bb][g] = 0.f;
+        for (int k = lane * 8; k < H; k += 512) {
+            bf16x8 wv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wv[g] = *(const bf16x8*)(w + (long long)g * H * H + k);
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                if (bb < nb) {
+                    const float* hp = a.h_prev + ((long long)d * a.B + b0 + bb) * H + k;
+                    const f32x4 h0 = *(const f32x4*)hp, h1 = *(const f32x4*)(hp + 4);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[bb][g] = fmaf(h0[e], bf16_to_f32(wv[g][e]), acc[bb][g]);
+                            acc[bb][g] = fmaf(h1[e], bf16_to_f32(wv[g][4 + e]), acc[bb][g]);
+                        }
+                }
             }
         }
+        float mine[4] = {0.f, 0.f, 0.f, 0.f};                     // lane bb keeps batch row b0 + bb
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float tot = wave_sum(acc[bb][g]);
+                if (lane == bb) mine[g] = tot;
+            }
+        if (lane < nb) {
+            const int b = b0 + lane;
+            const float* gx = a.gx + ((long long)b * a.T + t) * a.ld_gx + d * 4 * H + j;
+            const float gi = sigmoidf_(mine[0] + gx[0]);
+            const float gf = sigmoidf_(mine[1] + gx[H]);
+            const float gg = tanhf_(mine[2] + gx[2 * H]);
+            const float go = sigmoidf_(mine[3] + gx[3 * H]);
+            const long long si = ((long long)d * a.B + b) * H + j;
+            const float cn = gf * a.c[si] + gi * gg;
+            const float hn = go * tanhf_(cn);
+            a.c[si] = cn;
+            a.h_next[si] = hn;
+            short* yr = a.y + ((long long)b * a.T + t) * a.ld_y + d * H + j;
+            const short hi = f32_to_bf16(hn);
+            yr[0] = hi;
+            if (a.split_y) yr[2 * H] = f32_to_bf16(hn - bf16_to_f32(hi));
+            if (a.ysum) a.ysum[(long long)b * 2 * H + d * H + j] += hn * a.ysum_scale;
+        }
     }
-    const float* gx = a.gx + ((long long)b * a.T + t) * a.ld_gx + d * 4 * H + j;
-    const float gi = sigmoidf_(acc[0] + gx[0]);
-    const float gf = sigmoidf_(acc[1] + gx[H]);
-    const float gg = tanhf_(acc[2] + gx[2 * H]);
-    const float go = sigmoidf_(acc[3] + gx[3 * H]);
-    const long long si = ((long long)d * a.B + b) * H + j;
-    const float cn = gf * a.c[si] + gi * gg;
-    const float hn = go * tanhf_(cn);
-    a.c[si] = cn;
-    a.h_next[si] = hn;
-    short* yr = a.y + ((long long)b * a.T + t) * a.ld_y + d * H + j;
-    const short hi = f32_to_bf16(hn);
-    yr[0] = hi;
-    if (a.split_y) yr[2 * H] = f32_to_bf16(hn - bf16_to_f32(hi));
-    if (a.ysum) a.ysum[(long long)b * 2 * H + d * H + j] += hn * a.ysum_scale;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,7 +345,7 @@ extern "C" int asl_lstm_bidir_layer(const asl_lstm_params* p, const float* gx, c
     a.gx = gx; a.whh = (const short*)w_hh; a.c = state + 2 * n; a.y = (short*)y_bf16; a.ysum = ysum;
     a.B = p->batch; a.T = p->t; a.H = p->hidden; a.ld_gx = p->ld_gx; a.ld_y = p->ld_y;
     a.ysum_scale = p->ysum_scale; a.split_y = p->split_y;
-    const unsigned blocks = (unsigned)((n + 255) / 256);
+    const unsigned blocks = (unsigned)((2 * p->hidden + 3) / 4);      // one wave per (direction, unit)
     for (int step = 0; step < p->t; ++step) {
         a.h_prev = state + (step & 1) * n;
         a.h_next = state + ((step + 1) & 1) * n;
