@@ -276,7 +276,7 @@ int try_launch_conv3x3_c64(PatchArgs a, int n, hipStream_t stream) {
     if (!a.bmv) return -1;
     a.tiles_m = (a.M + a.bmv - 1) / a.bmv;
     a.tiles_n = 1;
-    int ncu = 256;
+    int ncu = device_cus();                            // one persistent workgroup per CU
     if (const char* e = getenv("ASL_C64_GRID")) ncu = atoi(e) > 0 ? atoi(e) : ncu;
     const int grid = a.tiles_m < ncu ? a.tiles_m : ncu;
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kC64Lds);

@@ -256,6 +256,17 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
 #endif
 }
 
+int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
 // Largest patch (pixels, halo included) any tile of bmv consecutive output pixels needs
 long long max_patch_pixels(int n, int h, int w, int in_halo, int bmv) {
     const int hp = h + 2 * in_halo, wp = w + 2 * in_halo;

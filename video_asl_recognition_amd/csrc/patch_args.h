@@ -32,6 +32,8 @@ struct PatchArgs {
     int stagger_ticks;     // one-time start delay (100 MHz ticks) of the second resident workgroup set
 };
 
+// compute units of the current device (cached per device; 256 when the query fails)
+int device_cus();
 long long max_patch_pixels(int n, int h, int w, int in_halo, int bmv);
 int patch_conv_tile(int n, int h, int w, int in_halo);
 // large-tile kernel (conv3x3_pp.hip): returns -1 when the request does not fit it

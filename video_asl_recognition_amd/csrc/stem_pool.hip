@@ -23,6 +23,7 @@
 
 #include "asl_hip.h"
 #include "common.h"
+#include "patch_args.h"
 
 namespace asl_detail {
 
@@ -202,7 +203,8 @@ extern "C" int asl_stem_pool_bf16(const asl_stem_pool_params* p, const void* x, 
     const long long blocks = (long long)p->n * a.tiles_x * a.tiles_y;
     if (blocks > 0x7fffffffLL) return ASL_EINVAL;
     // persistent grid: two 4-wave workgroups per CU fit the register budget (weights live in VGPRs)
-    const unsigned grid = (unsigned)(blocks < 512 ? blocks : 512);
+    const long long slots = 2LL * device_cus();
+    const unsigned grid = (unsigned)(blocks < slots ? blocks : slots);
     hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
