@@ -123,6 +123,34 @@ def test_full_size_linearity_property(gpu):
     torch.testing.assert_close(m(clips[:, perm]), y, rtol=1e-4, atol=1e-4)
 
 
+def test_chunking_and_streams_do_not_change_results(gpu):
+    """Ragged chunking over two streams (300 frames as 128 + 128 + 44), one stream, and one big chunk give the
+    same per-frame features bit for bit: every output pixel is computed by the same K-ordered sum whatever tile,
+    workgroup or stream it lands in."""
+    from video_asl_recognition_amd import AslClipModel
+    clips = O.make_clips(3, 100, 224, 4).cuda()
+    ref = None
+    for chunk, streams in ((512, 1), (128, 2), (128, 1), (77, 3)):
+        m = AslClipModel("resnet18_mean", frames_per_chunk=chunk, streams=streams, seed=3)
+        f, _ = m.frame_features(clips)
+        f = f.clone()
+        if ref is None:
+            ref = f
+        else:
+            assert torch.equal(f, ref), f"chunk={chunk} streams={streams} changed the features"
+        del m
+
+
+def test_single_frame_single_clip(gpu):
+    """smallest clip the surface accepts: B=1, T=1"""
+    om, m = _model("resnet18_mean")
+    clips = O.make_clips(1, 1, 224, 11)
+    y = m(clips.cuda()).cpu()
+    ref = om(clips)
+    assert torch.linalg.norm(y - ref) / torch.linalg.norm(ref) < 1e-3
+    assert int(y.argmax()) == int(ref.argmax())
+
+
 def test_resnet50_bilstm_matches_oracle(gpu):
     om, m = _model("resnet50_bilstm", frames_per_chunk=16)
     g = np.load(os.path.join(GOLDEN, "resnet50_bilstm_fwd_b2t8s224.npz"))
