@@ -44,11 +44,12 @@ struct PpShape {
     static constexpr int PLIVE = PIECES % 8 ? PCAP - 16 : PCAP;
     static constexpr int PATCH_BYTES = PCAP * 64;
     static constexpr int WST = TN * 64;                  // one weight stage: TN rows x 32 k
-    static constexpr int WPW = WST / 1024 / 8;           // weight DMA pieces per wave per stage
+    static constexpr int EW = WST / 1024 / 4;            // weight DMA pieces per EARLY wave per stage (waves 0-3 stream the weights)
+    static constexpr int PT = ((PIECES + 3) / 4 + 6) / 7; // patch pieces per LATE wave per tap (waves 4-7 stream the patch over taps 0-6)
     static constexpr int RING = FM == 8 ? 4 : 3;         // weight ring depth; prefetch distance RING - 1
     static constexpr int LDS = 2 * PATCH_BYTES + RING * WST;
     static constexpr int WAVES_PER_EU = FM == 8 ? 2 : 4;
-    static_assert(PPW >= 1 && PPW <= 7 && WPW >= 1, "piece counts");
+    static_assert(PPW >= 1 && EW >= 1 && PIECES % 4 == 0 && 4 * 9 * EW >= PIECES, "piece counts");
 };
 
 template <int FM_>
@@ -56,10 +57,12 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
 #if defined(__HIP_DEVICE_COMPILE__)
     using S = PpShape<FM_>;
     constexpr int WCO = S::WCO, FM = S::FM, FN = 4;
-    constexpr int PPW = S::PPW, WPW = S::WPW, WST = S::WST, RING = S::RING, DIST = RING - 1;
+    constexpr int PPW = S::PPW, EW = S::EW, PT = S::PT, WST = S::WST, RING = S::RING, DIST = RING - 1;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const ring = smem + 2 * S::PATCH_BYTES;
+    // weight ring first: its fragment reads then reach every slot through the instruction's 16-bit offset field
+    char* const ring = smem;
+    char* const patches = smem + S::RING * S::WST;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,31 +108,38 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
     // which holds 16-byte chunk (lane%4) ^ swz(p), swz(p) = (p & 4) >> 1 (conflict-free fragment reads
     // from any 16 consecutive pixels)
     const unsigned pvoff = (unsigned)((lane >> 2) * pix_bytes + 16 * ((lane & 3) ^ ((lane >> 3) & 2)));
-    auto dma_patch_piece = [&](int hc, int k) {         // piece (wave + 8k) of half-chunk hc
-        const int j = wave + 8 * k;
-        const bool live = hc < nhc && 16 * j < NP;      // else: zeros, into the piece itself or the spare last piece
-        const int jd = j < S::PIECES ? j : S::PIECES - 1;
-        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(16LL * j * pix_bytes + hc * 64));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(smem + (hc & 1) * S::PATCH_BYTES + jd * 1024),
-                                                 16, live ? pvoff : kOob, live ? so : 0u, 0, 0);
+    auto dma_patch_piece = [&](int hc, int j) {         // prologue only (half-chunk 0); pieces past the patch are skipped
+        if (16 * j < NP) {
+            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(16LL * j * pix_bytes + hc * 64));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(patches + (hc & 1) * S::PATCH_BYTES + j * 1024),
+                                                     16, pvoff, so, 0, 0);
+        }
     };
-    // weight piece q = wave * WPW + i covers tile rows 16q..16q+15 (64 B each); chunk swizzle (row & 8) ? 3 : 0
-    unsigned wvoff[WPW];
+    // weight piece q = (wave & 3) * EW + i covers tile rows 16q..16q+15 (64 B each); chunk swizzle (row & 8) ? 3 : 0
+    unsigned wvoff[EW];
 #pragma unroll
-    for (int i = 0; i < WPW; ++i) {
-        const int row = (wave * WPW + i) * 16 + (lane >> 2);
+    for (int i = 0; i < EW; ++i) {
+        const int row = ((wave & 3) * EW + i) * 16 + (lane >> 2);
         wvoff[i] = (unsigned)(2 * row * a.wk + 16 * ((lane & 3) ^ ((row & 8) ? 3 : 0)));
     }
-    auto dma_weights = [&](int s, int slot) {           // stage s = hc * 9 + tap -> ring slot s % RING
-        const bool live = s < nsteps;
+    auto dma_weights = [&](int s, int slot) {           // prologue only: stage s -> ring slot
         const int hc = s / 9, tap = s - 9 * hc;
-        const unsigned so = __builtin_amdgcn_readfirstlane(live ? (unsigned)(2 * (tap * a.C + hc * 32)) : 0u);
-        char* dst = ring + slot * WST + wave * (WPW * 1024);
+        char* dst = ring + slot * WST + (wave & 3) * (EW * 1024);
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(2 * (tap * a.C + hc * 32)));
 #pragma unroll
-        for (int i = 0; i < WPW; ++i)
+        for (int i = 0; i < EW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
-                                                     live ? wvoff[i] : kOob, so, 0, 0);
+                                                     s < nsteps ? wvoff[i] : kOob, so, 0, 0);
     };
+    // K-loop roles: waves 0-3 stream weight pieces, waves 4-7 patch pieces, through ONE instruction sequence whose
+    // descriptor and per-lane offsets are picked once per wave (scalar selects), so the roles cost no extra code.
+    const int w4 = wave & 3;
+    __amdgpu_buffer_rsrc_t krs = late ? xrs : wrs;
+    unsigned kvoff[EW];
+#pragma unroll
+    for (int i = 0; i < EW; ++i) kvoff[i] = late ? pvoff : wvoff[i];
+    const unsigned w4_patch_so = (unsigned)(16LL * w4 * pix_bytes);         // piece w4 of the patch
+    const unsigned quad_patch_so = (unsigned)(64LL * pix_bytes);            // four pieces further on
 
     // ---- per-lane fragment geometry ----------------------------------------------------------
     const int fr = lane & 15, fq = lane >> 4;
@@ -158,25 +168,33 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: patch of half-chunk 0, weight stages 0..2 ------------------------------------
+    // Roles in the K loop: the early half (waves 0-3) streams the weight stages, the late half (waves 4-7) the
+    // next half-chunk's patch.  vmcnt retires a wave's loads in issue order, so a wave that issued both would
+    // sit behind its slow patch pieces (HBM) every time it waits for the next weight stage (L2); split this way
+    // the per-step wait only ever covers weight pieces, and the patch is waited for once per half-chunk.
 #pragma unroll
-    for (int k = 0; k < PPW; ++k) dma_patch_piece(0, k);
+    for (int k = 0; k < PPW; ++k) dma_patch_piece(0, wave + 8 * k);
+    if (!late) {
 #pragma unroll
-    for (int d = 0; d < DIST; ++d) dma_weights(d, d);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DIST - 1) * WPW) : "memory");   // patch 0 and stage 0 landed
+        for (int d = 0; d < DIST; ++d) dma_weights(d, d);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * EW) : "memory");          // patch 0 pieces and stage 0 landed
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");
     if (late) asm volatile("s_barrier" ::: "memory");                                 // run one phase behind
 #if defined(ASL_STAMPS)
     st[1] = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- K loop ---------------------------------------------------------------------------------
-    // Step s: load phase L(s) = {DMA pieces of stage s+3 and of the next half-chunk's patch, the 12 fragment
-    // reads of step s, counted wait retiring stage s+1} | barrier | compute phase = 32 MFMAs | barrier.
-    // The wait leaves the pieces issued in L(s-1) and L(s) in flight: I(t) = WPW + (t < PPW) pieces in L of tap t.
+    // Step s: load phase L(s) = {this wave's DMA pieces (weight stage s + DIST, or a slice of the next half-chunk's
+    // patch), the fragment reads of step s, counted wait} | barrier | compute phase = the MFMAs | barrier.
 #if defined(ASL_STAMPS_PHASES)
     unsigned long long ph[4] = {0, 0, 0, 0};   // diagnostic: issue (DMA + reads), wait + barrier, MFMA issue, second barrier
 #endif
     int hc = 0;
-    const char* pbuf = smem;
+    const char* pbuf = patches;
     auto step = [&](auto tapc) {
         constexpr int tap = decltype(tapc)::value;
         const int s = hc * 9 + tap;
@@ -186,8 +204,31 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         // ring slot of step s: 9 = 0 (mod 3) and 9 = 1 (mod 4)
         const int slot = RING == 3 ? tap % 3 : ((hc + tap) & 3);
         const int slot_next = RING == 3 ? (tap + DIST) % 3 : ((hc + tap + DIST) & 3);
-        if constexpr (tap < PPW) dma_patch_piece(hc + 1, tap);
-        dma_weights(s + DIST, slot_next);
+        {
+            // early: stage s + DIST into ring slot slot_next, piece w4 * EW + i.  Past the last stage the pieces
+            // are still issued (the counted waits assume a fixed number): they read the first half-chunk of a
+            // later tap of the same weight rows, in bounds, into ring slots nobody reads any more.
+            // late: piece w4 + 4 (tap * EW + i) of half-chunk hc + 1's patch into the other patch buffer.  Pieces
+            // past the patch's last pixel, or of the half-chunk after the last, fetch neighbouring bytes of x
+            // (zeros beyond its end: the descriptor's range check) into space nobody reads.
+            const int tapn = (tap + DIST) % 9, hcn = hc + (tap + DIST) / 9;
+            const unsigned so_w = (unsigned)(2 * (tapn * a.C + hcn * 32));
+            char* const dst_w = ring + slot_next * WST + w4 * (EW * 1024);
+            char* const dst_p = patches + ((hc + 1) & 1) * S::PATCH_BYTES + w4 * 1024;
+#pragma unroll
+            for (int i = 0; i < EW; ++i) {
+                constexpr int quad = tap * EW;          // + i: which group of four patch pieces
+                if (4 * (quad + i) < S::PIECES) {
+                    const unsigned so_p = w4_patch_so + (quad + i) * quad_patch_so + (hc + 1) * 64;
+                    const unsigned so = __builtin_amdgcn_readfirstlane(late ? so_p : so_w);
+                    char* const dst = late ? dst_p + (quad + i) * 4096 : dst_w + i * 1024;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)dst, 16, kvoff[i], so, 0, 0);
+                } else if (!late) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(dst_w + i * 1024), 16,
+                                                             kvoff[i], __builtin_amdgcn_readfirstlane(so_w), 0, 0);
+                }
+            }
+        }
         const int toff = ((tap / 3 - 1) * a.Wp + (tap % 3 - 1)) * 64;
         const char* wb = ring + slot * WST;
         bf16x8 xf[FM], wf[FN];
@@ -202,14 +243,16 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
             t += toff;
             xf[i] = *(const bf16x8*)(pbuf + (t ^ ((t >> 3) & 0x20)));
         }
-        // pieces that may stay in flight: those of the last DIST - 1 load phases, this one included
-        constexpr int kPrev = tap == 0 ? 8 : tap - 1;
-        constexpr int kInFlight = (DIST == 3 ? (WPW + (kPrev < PPW ? 1 : 0)) : 0) + (WPW + (tap < PPW ? 1 : 0));
-        static_assert(DIST == 2 || DIST == 3, "wait counts are written for prefetch distance 2 or 3");
+        // early waves: the weight pieces of the last DIST - 1 load phases (this one included) may stay in flight;
+        // late waves: their patch pieces must have landed before the half-chunk's last barrier, nothing before that
+        constexpr int kInFlight = (DIST - 1) * EW;
 #if defined(ASL_STAMPS_PHASES)
         const unsigned long long tB = __builtin_amdgcn_s_memtime();
 #endif
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kInFlight) : "memory");
+        // (late waves have at most PT pieces per tap in flight ahead of this count, so outside tap 8 the same
+        // wait only ever holds them for a piece issued (DIST - 1) * EW / PT taps earlier)
+        if (tap == 8 && late) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kInFlight) : "memory");
 #if defined(ASL_STAMPS_PHASES)
         const unsigned long long tC = __builtin_amdgcn_s_memtime();
 #endif
@@ -233,7 +276,7 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
     };
 #pragma unroll 1
     for (hc = 0; hc < nhc; ++hc) {
-        pbuf = smem + (hc & 1) * S::PATCH_BYTES;
+        pbuf = patches + (hc & 1) * S::PATCH_BYTES;
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
         step(std::integral_constant<int, 2>{});
@@ -265,6 +308,8 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             int m = m0 + wp * (FM * 16) + i * 16 + fr;
+            asm volatile("" : "+v"(m));                  // recompute (n, y, x) here: reusing the prologue's values
+                                                        // would carry 3 registers per fragment across the K loop
             const bool ok = m < mend;
             m = ok ? m : mend - 1;
             const int n = (int)fdiv(m, a.dOHW), r1 = m - n * HW;
