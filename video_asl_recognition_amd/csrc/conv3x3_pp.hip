@@ -44,12 +44,11 @@ struct PpShape {
     static constexpr int PLIVE = PIECES % 8 ? PCAP - 16 : PCAP;
     static constexpr int PATCH_BYTES = PCAP * 64;
     static constexpr int WST = TN * 64;                  // one weight stage: TN rows x 32 k
-    static constexpr int EW = WST / 1024 / 4;            // weight DMA pieces per EARLY wave per stage (waves 0-3 stream the weights)
-    static constexpr int PT = ((PIECES + 3) / 4 + 6) / 7; // patch pieces per LATE wave per tap (waves 4-7 stream the patch over taps 0-6)
+    static constexpr int WPW = WST / 1024 / 8;           // weight DMA pieces per wave per stage
     static constexpr int RING = FM == 8 ? 4 : 3;         // weight ring depth; prefetch distance RING - 1
     static constexpr int LDS = 2 * PATCH_BYTES + RING * WST;
     static constexpr int WAVES_PER_EU = FM == 8 ? 2 : 4;
-    static_assert(PPW >= 1 && EW >= 1 && PIECES % 4 == 0 && 4 * 9 * EW >= PIECES, "piece counts");
+    static_assert(PPW >= 1 && PPW <= 7 && WPW >= 1, "piece counts");
 };
 
 template <int FM_>
@@ -57,7 +56,7 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
 #if defined(__HIP_DEVICE_COMPILE__)
     using S = PpShape<FM_>;
     constexpr int WCO = S::WCO, FM = S::FM, FN = 4;
-    constexpr int PPW = S::PPW, EW = S::EW, PT = S::PT, WST = S::WST, RING = S::RING, DIST = RING - 1;
+    constexpr int PPW = S::PPW, WPW = S::WPW, WST = S::WST, RING = S::RING, DIST = RING - 1;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // weight ring first: its fragment reads then reach every slot through the instruction's 16-bit offset field
@@ -104,52 +103,54 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
     __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wrec, 0x00020000);
     constexpr unsigned kOob = 0x80000000u;              // beyond num_records: the DMA writes zeros
 
-    // patch piece j covers patch pixels 16j..16j+15 (64 B each): lane -> pixel 16j + lane/4, slot lane%4,
-    // which holds 16-byte chunk (lane%4) ^ swz(p), swz(p) = (p & 4) >> 1 (conflict-free fragment reads
-    // from any 16 consecutive pixels)
-    const unsigned pvoff = (unsigned)((lane >> 2) * pix_bytes + 16 * ((lane & 3) ^ ((lane >> 3) & 2)));
-    auto dma_patch_piece = [&](int hc, int j) {         // prologue only (half-chunk 0); pieces past the patch are skipped
-        if (16 * j < NP) {
-            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(16LL * j * pix_bytes + hc * 64));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(patches + (hc & 1) * S::PATCH_BYTES + j * 1024),
-                                                     16, pvoff, so, 0, 0);
-        }
+    // Patch image in LDS: piece j (1 KiB) holds patch pixels 16j..16j+15 chunk-major, byte (p, c) at
+    // (p >> 4) * 1024 + c * 256 + (p & 15) * 16 (c = 16-byte chunk of the pixel's 64).  The 16-byte slot within
+    // the 256-byte bank row is p & 15 whatever the chunk, so a fragment read of 16 consecutive pixels is
+    // conflict-free with no address swizzle.  DMA lane -> pixel 16j + lane % 16, chunk lane / 16.
+    const unsigned pvoff = (unsigned)((lane & 15) * pix_bytes + (lane >> 4) * 16);
+    auto dma_patch_piece = [&](int hc, int k) {         // piece (wave + 8k) of half-chunk hc
+        const int j = wave + 8 * k;
+        const bool live = hc < nhc && 16 * j < NP;      // else: zeros, into the piece itself or the spare last piece
+        const int jd = j < S::PIECES ? j : S::PIECES - 1;
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(16LL * j * pix_bytes + hc * 64));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(patches + (hc & 1) * S::PATCH_BYTES + jd * 1024),
+                                                 16, live ? pvoff : kOob, live ? so : 0u, 0, 0);
     };
-    // weight piece q = (wave & 3) * EW + i covers tile rows 16q..16q+15 (64 B each); chunk swizzle (row & 8) ? 3 : 0
-    unsigned wvoff[EW];
+    // weight piece q = wave * WPW + i covers tile rows 16q..16q+15 (64 B each); chunk swizzle (row & 8) ? 3 : 0
+    unsigned wvoff[WPW];
 #pragma unroll
-    for (int i = 0; i < EW; ++i) {
-        const int row = ((wave & 3) * EW + i) * 16 + (lane >> 2);
+    for (int i = 0; i < WPW; ++i) {
+        const int row = (wave * WPW + i) * 16 + (lane >> 2);
         wvoff[i] = (unsigned)(2 * row * a.wk + 16 * ((lane & 3) ^ ((row & 8) ? 3 : 0)));
     }
-    auto dma_weights = [&](int s, int slot) {           // prologue only: stage s -> ring slot
+    auto dma_weights = [&](int s, int slot) {           // stage s = hc * 9 + tap -> ring slot s % RING
+        const bool live = s < nsteps;
         const int hc = s / 9, tap = s - 9 * hc;
-        char* dst = ring + slot * WST + (wave & 3) * (EW * 1024);
-        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(2 * (tap * a.C + hc * 32)));
+        const unsigned so = __builtin_amdgcn_readfirstlane(live ? (unsigned)(2 * (tap * a.C + hc * 32)) : 0u);
+        char* dst = ring + slot * WST + wave * (WPW * 1024);
 #pragma unroll
-        for (int i = 0; i < EW; ++i)
+        for (int i = 0; i < WPW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
-                                                     s < nsteps ? wvoff[i] : kOob, so, 0, 0);
+                                                     live ? wvoff[i] : kOob, so, 0, 0);
     };
-    // K-loop roles: waves 0-3 stream weight pieces, waves 4-7 patch pieces, through ONE instruction sequence whose
-    // descriptor and per-lane offsets are picked once per wave (scalar selects), so the roles cost no extra code.
-    const int w4 = wave & 3;
-    __amdgpu_buffer_rsrc_t krs = late ? xrs : wrs;
-    unsigned kvoff[EW];
-#pragma unroll
-    for (int i = 0; i < EW; ++i) kvoff[i] = late ? pvoff : wvoff[i];
-    const unsigned w4_patch_so = (unsigned)(16LL * w4 * pix_bytes);         // piece w4 of the patch
-    const unsigned quad_patch_so = (unsigned)(64LL * pix_bytes);            // four pieces further on
 
     // ---- per-lane fragment geometry ----------------------------------------------------------
     const int fr = lane & 15, fq = lane >> 4;
-    int pc[FM];                                         // byte offset of (centre pixel, chunk fq) in an unswizzled patch
+    // u[i]: image address of (top-left tap pixel, chunk 3) of this lane's pixel in fragment i.  The chunk field
+    // (bits 8-9) is all ones, so adding a tap's (pixel >> 4) << 10 | (pixel & 15) << 4 carries from the low
+    // pixel bits straight into the high ones; the lane's own chunk is then inserted over the field.
+    int u[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         int m = m0 + wp * (FM * 16) + i * 16 + fr;
         m = m < mend ? m : mend - 1;                    // idle slots recompute the tile's last pixel; never stored
-        pc[i] = (int)(centre(m) - P0) * 64 + fq * 16;
+        const int tl = (int)(centre(m) - P0) - a.Wp - 1;
+        u[i] = ((tl >> 4) << 10) | 0x300 | ((tl & 15) << 4);
     }
+    const int chunk_bits = fq << 8;
+    constexpr int chunk_mask = 0x300;
+    // LDS address of the dynamic segment's first byte
+    const int lds0 = (int)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
     // Weight rows are read in a permuted order so that a lane's accumulators for channel fragments 2h and
     // 2h+1 are eight CONSECUTIVE output channels of its pixel (MFMA row r of fragment j is channel
     // (j>>1)*32 + (r>>2)*8 + (j&1)*4 + (r&3) of the wave's 64): the epilogue stores 16 bytes per lane straight
@@ -168,33 +169,25 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: patch of half-chunk 0, weight stages 0..2 ------------------------------------
-    // Roles in the K loop: the early half (waves 0-3) streams the weight stages, the late half (waves 4-7) the
-    // next half-chunk's patch.  vmcnt retires a wave's loads in issue order, so a wave that issued both would
-    // sit behind its slow patch pieces (HBM) every time it waits for the next weight stage (L2); split this way
-    // the per-step wait only ever covers weight pieces, and the patch is waited for once per half-chunk.
 #pragma unroll
-    for (int k = 0; k < PPW; ++k) dma_patch_piece(0, wave + 8 * k);
-    if (!late) {
+    for (int k = 0; k < PPW; ++k) dma_patch_piece(0, k);
 #pragma unroll
-        for (int d = 0; d < DIST; ++d) dma_weights(d, d);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * EW) : "memory");          // patch 0 pieces and stage 0 landed
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_barrier" ::: "memory");
+    for (int d = 0; d < DIST; ++d) dma_weights(d, d);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DIST - 1) * WPW) : "memory");   // patch 0 and stage 0 landed
     if (late) asm volatile("s_barrier" ::: "memory");                                 // run one phase behind
 #if defined(ASL_STAMPS)
     st[1] = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- K loop ---------------------------------------------------------------------------------
-    // Step s: load phase L(s) = {this wave's DMA pieces (weight stage s + DIST, or a slice of the next half-chunk's
-    // patch), the fragment reads of step s, counted wait} | barrier | compute phase = the MFMAs | barrier.
+    // Step s: load phase L(s) = {DMA pieces of stage s+3 and of the next half-chunk's patch, the 12 fragment
+    // reads of step s, counted wait retiring stage s+1} | barrier | compute phase = 32 MFMAs | barrier.
+    // The wait leaves the pieces issued in L(s-1) and L(s) in flight: I(t) = WPW + (t < PPW) pieces in L of tap t.
 #if defined(ASL_STAMPS_PHASES)
     unsigned long long ph[4] = {0, 0, 0, 0};   // diagnostic: issue (DMA + reads), wait + barrier, MFMA issue, second barrier
 #endif
     int hc = 0;
-    const char* pbuf = patches;
+    int pboff = lds0 + (int)(S::RING * S::WST);        // LDS address of the current half-chunk's patch image
     auto step = [&](auto tapc) {
         constexpr int tap = decltype(tapc)::value;
         const int s = hc * 9 + tap;
@@ -204,55 +197,33 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         // ring slot of step s: 9 = 0 (mod 3) and 9 = 1 (mod 4)
         const int slot = RING == 3 ? tap % 3 : ((hc + tap) & 3);
         const int slot_next = RING == 3 ? (tap + DIST) % 3 : ((hc + tap + DIST) & 3);
-        {
-            // early: stage s + DIST into ring slot slot_next, piece w4 * EW + i.  Past the last stage the pieces
-            // are still issued (the counted waits assume a fixed number): they read the first half-chunk of a
-            // later tap of the same weight rows, in bounds, into ring slots nobody reads any more.
-            // late: piece w4 + 4 (tap * EW + i) of half-chunk hc + 1's patch into the other patch buffer.  Pieces
-            // past the patch's last pixel, or of the half-chunk after the last, fetch neighbouring bytes of x
-            // (zeros beyond its end: the descriptor's range check) into space nobody reads.
-            const int tapn = (tap + DIST) % 9, hcn = hc + (tap + DIST) / 9;
-            const unsigned so_w = (unsigned)(2 * (tapn * a.C + hcn * 32));
-            char* const dst_w = ring + slot_next * WST + w4 * (EW * 1024);
-            char* const dst_p = patches + ((hc + 1) & 1) * S::PATCH_BYTES + w4 * 1024;
-#pragma unroll
-            for (int i = 0; i < EW; ++i) {
-                constexpr int quad = tap * EW;          // + i: which group of four patch pieces
-                if (4 * (quad + i) < S::PIECES) {
-                    const unsigned so_p = w4_patch_so + (quad + i) * quad_patch_so + (hc + 1) * 64;
-                    const unsigned so = __builtin_amdgcn_readfirstlane(late ? so_p : so_w);
-                    char* const dst = late ? dst_p + (quad + i) * 4096 : dst_w + i * 1024;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)dst, 16, kvoff[i], so, 0, 0);
-                } else if (!late) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(dst_w + i * 1024), 16,
-                                                             kvoff[i], __builtin_amdgcn_readfirstlane(so_w), 0, 0);
-                }
-            }
-        }
-        const int toff = ((tap / 3 - 1) * a.Wp + (tap % 3 - 1)) * 64;
+        if constexpr (tap < PPW) dma_patch_piece(hc + 1, tap);
+        dma_weights(s + DIST, slot_next);
+        const int o = (tap / 3) * a.Wp + tap % 3;       // tap pixel relative to the top-left one
+        const int so = __builtin_amdgcn_readfirstlane((((o >> 4) << 10) | ((o & 15) << 4)) + pboff);
         const char* wb = ring + slot * WST;
         bf16x8 xf[FM], wf[FN];
 #pragma unroll
         for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(wb + wrd[j]);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            // byte offset t = 64 p + 16 fq; the chunk swizzle (p & 4) >> 1 is bit 8 of t moved to bit 5.
-            // The empty asm keeps the compiler from hoisting 72 tap addresses out of the K loop into VGPRs.
-            int t = pc[i];
-            asm volatile("" : "+v"(t));
-            t += toff;
-            xf[i] = *(const bf16x8*)(pbuf + (t ^ ((t >> 3) & 0x20)));
+            // two vector instructions per address (the K loop is bound by vector issue, not by the MFMA pipe).
+            // The tap term passes through an empty asm per use: otherwise the compiler hoists all 72 tap
+            // addresses out of the K loop into registers.
+            int so_i = so;
+            asm volatile("" : "+s"(so_i));
+            const int r = u[i] + so_i;
+            const int ad = (r & ~chunk_mask) | chunk_bits;
+            xf[i] = *(const __attribute__((address_space(3))) bf16x8*)(unsigned long long)(unsigned)ad;
         }
-        // early waves: the weight pieces of the last DIST - 1 load phases (this one included) may stay in flight;
-        // late waves: their patch pieces must have landed before the half-chunk's last barrier, nothing before that
-        constexpr int kInFlight = (DIST - 1) * EW;
+        // pieces that may stay in flight: those of the last DIST - 1 load phases, this one included
+        constexpr int kPrev = tap == 0 ? 8 : tap - 1;
+        constexpr int kInFlight = (DIST == 3 ? (WPW + (kPrev < PPW ? 1 : 0)) : 0) + (WPW + (tap < PPW ? 1 : 0));
+        static_assert(DIST == 2 || DIST == 3, "wait counts are written for prefetch distance 2 or 3");
 #if defined(ASL_STAMPS_PHASES)
         const unsigned long long tB = __builtin_amdgcn_s_memtime();
 #endif
-        // (late waves have at most PT pieces per tap in flight ahead of this count, so outside tap 8 the same
-        // wait only ever holds them for a piece issued (DIST - 1) * EW / PT taps earlier)
-        if (tap == 8 && late) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kInFlight) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kInFlight) : "memory");
 #if defined(ASL_STAMPS_PHASES)
         const unsigned long long tC = __builtin_amdgcn_s_memtime();
 #endif
@@ -276,7 +247,7 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
     };
 #pragma unroll 1
     for (hc = 0; hc < nhc; ++hc) {
-        pbuf = patches + (hc & 1) * S::PATCH_BYTES;
+        pboff = lds0 + (int)(S::RING * S::WST) + (hc & 1) * S::PATCH_BYTES;
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
         step(std::integral_constant<int, 2>{});
