@@ -133,7 +133,8 @@ def main():
                        "parallelism": f"batch-sharded x{world}, all-gather of logits"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv MFMA kernels (stem_pool_kernel, conv3x3_c64_kernel, conv3x3_pp_kernel, gather_gemm_kernel), "
+                "kernel": "conv MFMA kernels (stem_pool_kernel, conv3x3_c64_kernel, conv3x3_pp_kernel, conv3x3_wide_kernel, "
+                          "gather_gemm_kernel), "
                           "all conv launches of one step",
                 "achieved": round(achieved, 2),
                 "peak": MFMA_PEAK_TFLOPS,
@@ -155,7 +156,8 @@ def main():
         dist.destroy_process_group()
 
 
-CONV_KERNELS = ("stem_pool_kernel", "conv3x3_c64_kernel", "conv3x3_pp_kernel", "conv3x3_patch_kernel", "gather_gemm_kernel")
+CONV_KERNELS = ("stem_pool_kernel", "conv3x3_c64_kernel", "conv3x3_pp_kernel", "conv3x3_wide_kernel", "conv3x3_patch_kernel",
+                "gather_gemm_kernel")
 
 
 def pmc_traffic_per_launch(path=os.path.join(ROOT, "profiles", "r01_final_pmc_summary.csv")):

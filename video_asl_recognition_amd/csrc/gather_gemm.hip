@@ -318,6 +318,8 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
             b.dOW = a.dOW; b.dOHW = a.dOHW; b.dODHW = a.dODHW;
             int r = try_launch_conv3x3_c64(b, p->nb, s);           // 64 -> 64: persistent, weights resident in LDS
             if (r >= 0) return r;
+            r = try_launch_conv3x3_wide(b, p->nb, s);              // C >= 128: 16-wave workgroup, 512 x 128 tile
+            if (r >= 0) return r;
             r = try_launch_conv3x3_pp(b, p->nb, s);                // C >= 128: 8-wave ping-pong workgroups
             if (r >= 0) return r;
             if ((b.bmv = patch_conv_tile(p->nb, p->oh, p->ow, halo)) > 0) return launch_conv3x3_patch(b, s);

@@ -37,6 +37,7 @@ int device_cus();
 long long max_patch_pixels(int n, int h, int w, int in_halo, int bmv);
 int patch_conv_tile(int n, int h, int w, int in_halo);
 // large-tile kernel (conv3x3_pp.hip): returns -1 when the request does not fit it
+int try_launch_conv3x3_wide(PatchArgs a, int n, hipStream_t stream);
 int try_launch_conv3x3_pp(PatchArgs a, int n, hipStream_t stream);
 // persistent 64 -> 64 channel kernel (conv3x3_c64.hip): returns -1 when the request does not fit it
 int try_launch_conv3x3_c64(PatchArgs a, int n, hipStream_t stream);
