@@ -143,6 +143,26 @@ def test_stem_conv_and_pack_clips(gpu):
     _assert_bf16_close(_unhalo(yd, 1), ref)
 
 
+@pytest.mark.parametrize("s,halo", [(8, 0), (8, 1), (12, 2), (64, 3), (224, 3), (112, 1), (6, 3), (20, 5)])
+def test_pack_clips_bf16_layout_exact(gpu, s, halo):
+    """bf16 clips -> packed 4-channel halo'd image, bit for bit, halo cells written as zeros (the destination is
+    poisoned first); covers the 8-pixel-per-lane kernel (s % 4 == 0, aligned source), every halo parity, and the
+    generic kernel for s % 4 != 0 and for a source that is only 2-byte aligned"""
+    from video_asl_recognition_amd import _lib as L
+    n = 3
+    g = torch.Generator().manual_seed(s * 7 + halo)
+    clips = _bf16(torch.randn(n, 3, s, s, generator=g))
+    want = F.pad(torch.cat([clips, torch.zeros(n, 1, s, s)], 1).permute(0, 2, 3, 1), (0, 0, halo, halo, halo, halo))
+    src = clips.cuda().to(torch.bfloat16).contiguous()
+    shifted = torch.empty(src.numel() + 1, dtype=torch.bfloat16, device="cuda")
+    shifted[1:] = src.flatten()
+    for ptr in (src, shifted[1:]):
+        x0 = torch.full((n, s + 2 * halo, s + 2 * halo, 4), 7.0, dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib.asl_pack_clips(_p(ptr), 0, n, s, halo, _p(x0), None))
+        torch.cuda.synchronize()
+        assert torch.equal(x0.float().cpu(), want)
+
+
 def test_maxpool_exact(gpu):
     from video_asl_recognition_amd import _lib as L
     x = _bf16(torch.rand(2, 64, 30, 22) * 4)

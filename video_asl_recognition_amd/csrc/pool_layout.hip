@@ -43,6 +43,58 @@ __global__ __launch_bounds__(256) void pack_clips_kernel(const void* __restrict_
     }
 }
 
+// bf16 clips, s % 4 == 0, 8-byte aligned: one lane per 8 output pixels (64 B).  Per channel the lane reads
+// three aligned 8-byte words around its 8 source pixels (the halo shifts a row by an odd number of pixels,
+// so the sources are only 2-byte aligned) and funnel-shifts them into place; 9 loads and 4 stores per 64 B
+// against 24 two-byte loads for the same bytes in the generic kernel.
+__global__ __launch_bounds__(256) void pack_clips_bf16x8_kernel(const short* __restrict__ clips, int n, int s, int kHalo0,
+                                                                short* __restrict__ y) {
+    const int sp = s + 2 * kHalo0;
+    const int groups = (sp + 7) >> 3;
+    const long long total = (long long)n * sp * groups;
+    const long long plane = (long long)s * s;
+    const int e_off = ((-kHalo0) % 4 + 4) % 4;          // first source pixel of a group relative to its aligned word
+    const int shr = 16 * e_off;
+    typedef unsigned long long u64;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % groups);
+        const long long t = i / groups;
+        const int py = (int)(t % sp);
+        const long long img = t / sp;
+        const int px0 = g * 8, yy = py - kHalo0;
+        u64 v[3][2] = {{0, 0}, {0, 0}, {0, 0}};           // [channel][pixels 0-3 | 4-7]
+        if (yy >= 0 && yy < s) {
+            const int e0 = px0 - kHalo0 - e_off;         // multiple of 4 (may be negative)
+            const short* row = clips + img * 3 * plane + (long long)yy * s;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                u64 w[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int e = e0 + 4 * k;
+                    w[k] = (e >= 0 && e + 4 <= s) ? *(const u64*)(row + c * plane + e) : 0ull;
+                }
+                v[c][0] = shr ? (w[0] >> shr) | (w[1] << (64 - shr)) : w[0];
+                v[c][1] = shr ? (w[1] >> shr) | (w[2] << (64 - shr)) : w[1];
+            }
+        }
+        short* dst = y + (((img * sp + py) * sp) + px0) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                    // two pixels per 16-byte store
+            if (px0 + 2 * q < sp) {
+                const int h = q >> 1, sh0 = 32 * (q & 1);
+                const unsigned a0 = (unsigned)(v[0][h] >> sh0), a1 = (unsigned)(v[1][h] >> sh0), a2 = (unsigned)(v[2][h] >> sh0);
+                i32x4 o;
+                o[0] = (int)((a0 & 0xffffu) | (a1 << 16));
+                o[1] = (int)(a2 & 0xffffu);
+                o[2] = (int)((a0 >> 16) | (a1 & 0xffff0000u));
+                o[3] = (int)(a2 >> 16);
+                *(i32x4*)(dst + 8 * q) = o;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // uint8 frames [n][h0][w0][3] -> bilinear resize -> /255 -> (x-mean)/std -> packed bf16
 // Source index and weights follow ATen's area_pixel_compute_source_index /
@@ -306,7 +358,10 @@ extern "C" int asl_pack_clips(const void* clips, int in_f32, int n, int s, int h
     const long long total = (long long)n * (s + 2 * halo) * ((s + 2 * halo) / 2);
     hipStream_t st = (hipStream_t)stream;
     if (in_f32) hipLaunchKernelGGL(pack_clips_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, halo, (short*)y);
-    else hipLaunchKernelGGL(pack_clips_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, halo, (short*)y);
+    else if ((s & 3) == 0 && ((uintptr_t)clips & 7) == 0) {
+        const long long items = (long long)n * (s + 2 * halo) * ((s + 2 * halo + 7) / 8);
+        hipLaunchKernelGGL(pack_clips_bf16x8_kernel, dim3(grid_for(items)), dim3(256), 0, st, (const short*)clips, n, s, halo, (short*)y);
+    } else hipLaunchKernelGGL(pack_clips_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, halo, (short*)y);
     return (int)hipGetLastError();
 }
 
