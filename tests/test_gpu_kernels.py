@@ -67,7 +67,8 @@ def test_conv2d_bn_res_relu(gpu, n, h, w, cin, cout, k, stride, pad, res, relu):
 
 # Every 3x3 / stride 1 kernel variant on the shapes it takes (the library reads these switches per call):
 # the 16-wave 512 x 128 kernel from 128 channels up, the 8-wave 256 x 128 one alone, and its 512-pixel form.
-KERNEL_SWITCHES = [{"ASL_WIDE_MIN_C": "128"}, {"ASL_NO_WIDE_CONV": "1"}, {"ASL_NO_WIDE_CONV": "1", "ASL_PP_BIG": "1"}]
+KERNEL_SWITCHES = [{"ASL_WIDE_MIN_C": "128", "ASL_WIDE_ANY_GRID": "1"}, {"ASL_NO_WIDE_CONV": "1"},
+                   {"ASL_NO_WIDE_CONV": "1", "ASL_PP_BIG": "1"}]
 LARGE_TILE_CASES = [
     (9, 28, 28, 128, 128, 3, 1, 1, True, True),      # tiles straddle rows and images, partial last tile
     (20, 28, 28, 128, 256, 3, 1, 1, False, False),   # two channel tiles, no residual, no ReLU
@@ -80,7 +81,7 @@ LARGE_TILE_CASES = [
 @pytest.mark.parametrize("switches", KERNEL_SWITCHES, ids=["wide16", "twin", "big"])
 @pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,res,relu", LARGE_TILE_CASES)
 def test_large_tile_conv_variants(gpu, monkeypatch, switches, n, h, w, cin, cout, k, stride, pad, res, relu):
-    for name in ("ASL_WIDE_MIN_C", "ASL_NO_WIDE_CONV", "ASL_PP_BIG"):
+    for name in ("ASL_WIDE_MIN_C", "ASL_WIDE_ANY_GRID", "ASL_NO_WIDE_CONV", "ASL_PP_BIG"):
         monkeypatch.delenv(name, raising=False)
     for name, v in switches.items():
         monkeypatch.setenv(name, v)
