@@ -75,6 +75,9 @@ LARGE_TILE_CASES = [
     (40, 14, 14, 256, 256, 3, 1, 1, True, True),
     (31, 7, 7, 512, 512, 3, 1, 1, True, True),       # whole-image tiles, last tile short
     (1, 14, 14, 256, 128, 3, 1, 1, True, False),     # a single, mostly idle tile
+    (6, 20, 20, 192, 384, 3, 1, 1, True, True),      # six half-chunks, three channel tiles
+    (3, 12, 17, 320, 128, 3, 1, 1, False, True),     # ten half-chunks, odd width: every fragment straddles rows
+    (2, 40, 36, 128, 128, 3, 1, 1, True, True),      # rows wider than a 16-pixel fragment, tiles cut mid-row
 ]
 
 
