@@ -220,6 +220,10 @@ def test_clip_stream_equals_direct_classification(gpu):
     assert len(streamed) == 3
     for (i0, p0), (i1, p1) in zip(direct, streamed):
         assert torch.equal(i0, i1) and torch.equal(p0, p1)
+    pinned = list(clipio.ClipStream(m, topk=3)([b.pin_memory() for b in batches]))     # transferred without staging
+    torch.cuda.synchronize()
+    for (i0, p0), (i1, p1) in zip(direct, pinned):
+        assert torch.equal(i0, i1) and torch.equal(p0, p1)
     assert list(clipio.ClipStream(m)([])) == []
 
 

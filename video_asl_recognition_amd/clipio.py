@@ -201,9 +201,12 @@ class ClipStream:
             self._free[slot] = None
         if self._free[slot] is not None:
             self._free[slot].synchronize()        # the previous user of this slot has finished reading it
-        self._pin[slot].copy_(batch)
+        src = batch
+        if not batch.is_pinned():                 # pageable memory: stage it (a pinned batch is transferred as it is
+            self._pin[slot].copy_(batch)          # and must stay untouched until its result has been yielded)
+            src = self._pin[slot]
         with torch.cuda.stream(self._copy):
-            self._dev[slot].copy_(self._pin[slot], non_blocking=True)
+            self._dev[slot].copy_(src, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._copy)
         return ev
