@@ -105,42 +105,86 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
                                                          float i1, float i2, short* __restrict__ y,
                                                          float* __restrict__ clips_f32) {
     const int sp = s + 2 * kHalo0;
-    const long long total = (long long)n * sp * sp;
     const float sy = (float)h0 / (float)s, sx = (float)w0 / (float)s;
-    const float mean[3] = {m0, m1, m2}, sd[3] = {i0, i1, i2};
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int px = (int)(i % sp);
-        const long long t = i / sp;
-        const int py = (int)(t % sp);
-        const long long img = t / sp;
-        bf16x4 o = {0, 0, 0, 0};
-        const int oy = py - kHalo0, ox = px - kHalo0;
-        if (oy >= 0 && oy < s && ox >= 0 && ox < s) {
-            float fy = sy * ((float)oy + 0.5f) - 0.5f;
-            float fx = sx * ((float)ox + 0.5f) - 0.5f;
-            fy = fy < 0.f ? 0.f : fy;
-            fx = fx < 0.f ? 0.f : fx;
-            int y0 = (int)fy, x0 = (int)fx;
-            y0 = y0 < h0 - 1 ? y0 : h0 - 1;
-            x0 = x0 < w0 - 1 ? x0 : w0 - 1;
-            const int y1 = y0 + (y0 < h0 - 1 ? 1 : 0), x1 = x0 + (x0 < w0 - 1 ? 1 : 0);
-            const float ly = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
-            const float hy = 1.f - ly, hx = 1.f - lx;
-            const uint8_t* f = frames + img * (long long)h0 * w0 * 3;
-            const uint8_t* p00 = f + ((long long)y0 * w0 + x0) * 3;
-            const uint8_t* p01 = f + ((long long)y0 * w0 + x1) * 3;
-            const uint8_t* p10 = f + ((long long)y1 * w0 + x0) * 3;
-            const uint8_t* p11 = f + ((long long)y1 * w0 + x1) * 3;
+    // 1/255 and 1/std as multiplications: a true fp32 division is ~10 instructions and the kernel does six per
+    // pixel; the result differs from (v / 255 - mean) / std by at most 2 ulp of fp32
+    const float mean[3] = {m0, m1, m2}, isd[3] = {1.f / i0, 1.f / i1, 1.f / i2};
+    const float inv255 = 1.f / 255.f;
+    const long long frame_bytes = (long long)n * h0 * w0 * 3;
+    // A workgroup takes kRows consecutive output rows (row index and vertical weights are wave-uniform), lanes
+    // run along the row; a lane first issues the source loads of all its rows, then blends and stores: one load
+    // round trip per kRows pixels instead of one per pixel (the kernel is bound by that latency, not by bytes).
+    constexpr int kRows = 4;
+    const unsigned rows = (unsigned)n * (unsigned)sp;       // < 2^31: checked on the host
+    const unsigned groups = (rows + kRows - 1) / kRows;
+    for (unsigned grp = blockIdx.x; grp < groups; grp += gridDim.x)
+    for (int px = threadIdx.x; px < sp; px += 256) {
+        const int ox = px - kHalo0;
+        const bool col_in = ox >= 0 && ox < s;
+        float fx = sx * ((float)ox + 0.5f) - 0.5f;
+        fx = fx < 0.f ? 0.f : fx;
+        int x0 = (int)fx;
+        x0 = x0 < w0 - 1 ? x0 : w0 - 1;
+        const int x1 = x0 + (x0 < w0 - 1 ? 1 : 0);
+        const float lx = fminf(fmaxf(fx - (float)x0, 0.f), 1.f), hx = 1.f - lx;
+        unsigned long long q0[kRows], q1[kRows];
+        float ly[kRows];
+        bool live[kRows];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v = hy * (hx * (float)p00[c] + lx * (float)p01[c]) +
-                                ly * (hx * (float)p10[c] + lx * (float)p11[c]);
-                const float z = (v / 255.0f - mean[c]) / sd[c];
-                o[c] = f32_to_bf16(z);
-                if (clips_f32) clips_f32[((img * 3 + c) * s + oy) * (long long)s + ox] = z;
+        for (int r = 0; r < kRows; ++r) {
+            const unsigned row = grp * kRows + r;
+            const unsigned img = row / (unsigned)sp;
+            const int oy = (int)(row - img * sp) - kHalo0;
+            live[r] = row < rows && col_in && oy >= 0 && oy < s;
+            q0[r] = q1[r] = 0;
+            ly[r] = 0.f;
+            if (live[r]) {
+                float fy = sy * ((float)oy + 0.5f) - 0.5f;
+                fy = fy < 0.f ? 0.f : fy;
+                int y0 = (int)fy;
+                y0 = y0 < h0 - 1 ? y0 : h0 - 1;
+                const int y1 = y0 + (y0 < h0 - 1 ? 1 : 0);
+                ly[r] = fminf(fmaxf(fy - (float)y0, 0.f), 1.f);
+                const long long fo = (long long)img * h0 * w0 * 3;
+                const long long o0 = fo + ((long long)y0 * w0 + x0) * 3, o1 = fo + ((long long)y1 * w0 + x0) * 3;
+                // the two source pixels of a row are 6 consecutive bytes: one unaligned 8-byte load per row instead
+                // of six byte loads (not in the last column, where x1 == x0, nor within 8 bytes of the tensor's end)
+                if (x1 == x0 + 1 && o1 + 8 <= frame_bytes) {
+                    struct __attribute__((packed)) U64 { unsigned long long v; };
+                    q0[r] = ((const U64*)(frames + o0))->v;
+                    q1[r] = ((const U64*)(frames + o1))->v;
+                } else {
+                    const uint8_t* a0 = frames + o0;
+                    const uint8_t* a1 = frames + o1;
+                    const int d = (x1 - x0) * 3;
+                    q0[r] = (unsigned long long)a0[0] | ((unsigned long long)a0[1] << 8) | ((unsigned long long)a0[2] << 16) |
+                            ((unsigned long long)a0[d] << 24) | ((unsigned long long)a0[d + 1] << 32) | ((unsigned long long)a0[d + 2] << 40);
+                    q1[r] = (unsigned long long)a1[0] | ((unsigned long long)a1[1] << 8) | ((unsigned long long)a1[2] << 16) |
+                            ((unsigned long long)a1[d] << 24) | ((unsigned long long)a1[d + 1] << 32) | ((unsigned long long)a1[d + 2] << 40);
+                }
             }
         }
-        *(bf16x4*)(y + 4 * i) = o;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const unsigned row = grp * kRows + r;
+            if (row >= rows) break;
+            const unsigned img = row / (unsigned)sp;
+            const int oy = (int)(row - img * sp) - kHalo0;
+            bf16x4 o = {0, 0, 0, 0};
+            if (live[r]) {
+                const float hy = 1.f - ly[r];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v00 = (float)(unsigned)((q0[r] >> (8 * c)) & 0xff), v01 = (float)(unsigned)((q0[r] >> (8 * c + 24)) & 0xff);
+                    const float v10 = (float)(unsigned)((q1[r] >> (8 * c)) & 0xff), v11 = (float)(unsigned)((q1[r] >> (8 * c + 24)) & 0xff);
+                    const float v = hy * (hx * v00 + lx * v01) + ly[r] * (hx * v10 + lx * v11);
+                    const float z = (v * inv255 - mean[c]) * isd[c];
+                    o[c] = f32_to_bf16(z);
+                    if (clips_f32) clips_f32[(((long long)img * 3 + c) * s + oy) * (long long)s + ox] = z;
+                }
+            }
+            *(bf16x4*)(y + 4 * ((long long)row * sp + px)) = o;
+        }
     }
 }
 
@@ -371,8 +415,9 @@ extern "C" int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, i
         return ASL_EINVAL;
     for (int c = 0; c < 3; ++c)
         if (!(std_[c] > 0.f)) return ASL_EINVAL;
-    const long long total = (long long)n * (s + 2 * halo) * (s + 2 * halo);
-    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, frames, n, h0, w0,
+    if ((long long)n * (s + 2 * halo) >= 0x7fffffffLL) return ASL_EINVAL;
+    const long long rows = ((long long)n * (s + 2 * halo) + 3) / 4;     // four output rows per workgroup
+    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)(rows < (1 << 20) ? rows : (1 << 20))), dim3(256), 0, (hipStream_t)stream, frames, n, h0, w0,
                        s, halo, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], (short*)y,
                        clips_f32);
     return (int)hipGetLastError();
