@@ -2,7 +2,11 @@
 """Benchmark of the clip -> logits hot path: ResNet-18 per-frame backbone + mean over T +
 Linear(512,100), T=64, 224x224, bf16, synthetic clips resident in HBM.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+For N>1 the command may be started either way: under torch.distributed.run (WORLD_SIZE etc. in the
+environment: this process is one rank), or bare -- then this process touches no GPU, starts the N
+ranks itself through torch.distributed.run on 127.0.0.1, and exits with their return code.
 
 A step = one forward() over one batch of `--clips` clips per GPU (pack -> stem -> maxpool ->
 20 convs -> avg-pool -> mean over T -> head) plus, for N>1, the RCCL all-gather of the logits.
@@ -22,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2516.6            # 256 CU x 4096 bf16 FLOP/clk/CU x 2.4 GHz, dense
+HBM_PEAK_GBPS = 8000.0               # HBM3E spec
 R18_CONV_MAC_PER_FRAME = 1_813_561_344   # conv MACs only, unpadded, 224x224
 
 
@@ -49,13 +54,20 @@ def main():
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("ASL_CHUNK", "256")))
     ap.add_argument("--streams", type=int, default=int(os.environ.get("ASL_STREAMS", "2")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="launcher / rendezvous / reporting path only: gloo on CPU with a stand-in step "
+                         "(no kernels; the JSON line says so and is not a measurement)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.cpu_dry_run:
+        return dry_run(args, world, rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -112,8 +124,20 @@ def main():
         conv_ms, launches = time_conv_launches(model, clips, passes=3)
         flops_step = conv_flops_per_frame(model) * B * T
         assert conv_flops_per_frame(model) == 2 * R18_CONV_MAC_PER_FRAME
-        achieved = flops_step / (conv_ms * 1e-3) / 1e12
-        traffic, traffic_note = pmc_traffic_per_launch()
+        step_s = elapsed / args.steps
+        # `frac` prices the schedule that was timed: the step's conv FLOPs over the step's wall time (chunks
+        # overlap on `streams` HIP streams, so per-launch durations cannot simply be added up); the
+        # event-bracketed serial pass (each conv launch alone on one stream) is kept as serial_*.
+        achieved = flops_step / step_s / 1e12
+        serial = flops_step / (conv_ms * 1e-3) / 1e12
+        chunks_per_step = -(-B * T // min(args.chunk, -(-B * T // max(1, args.streams))))
+        ctr = profiled_counters()
+        traffic = hbm_gbps = mfma_busy = None
+        if ctr:
+            step_bytes = ctr["hbm_bytes_per_chunk"] * ctr.get("chunk_scale", 1.0) * chunks_per_step
+            traffic = round(step_bytes / launches)
+            hbm_gbps = round(step_bytes / step_s / 1e9, 1)
+            mfma_busy = ctr.get("mfma_busy")
         result = {
             "metric": "clips/sec end-to-end (T=64, 224x224, bf16)",
             "value": round(clips_per_s, 2),
@@ -121,7 +145,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": round(step_s * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -133,19 +157,23 @@ def main():
                        "parallelism": f"batch-sharded x{world}, all-gather of logits"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv MFMA kernels (stem_pool_kernel, conv3x3_c64_kernel, conv3x3_pp_kernel, conv3x3_wide_kernel, "
-                          "gather_gemm_kernel), "
-                          "all conv launches of one step",
+                "kernel": "the conv MFMA kernels of one step (stem_pool, conv3x3_c64, conv3x3_pp / conv3x3_wide, "
+                          "gather_gemm), as scheduled in the timed region",
                 "achieved": round(achieved, 2),
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic,
-                "traffic_note": traffic_note,
+                "traffic_note": (ctr or {}).get("note", "no committed counter summary found"),
+                "hbm_gbps": hbm_gbps,
+                "hbm_peak_gbps": HBM_PEAK_GBPS,
+                "hbm_frac": None if hbm_gbps is None else round(hbm_gbps / HBM_PEAK_GBPS, 4),
+                "mfma_busy": mfma_busy,
                 "launches_per_step": launches,
-                "avg_launch_us": round(conv_ms * 1e3 / launches, 2),
                 "algorithmic_gflop_per_step": round(flops_step / 1e9, 1),
-                "end_to_end_frac": round(clips_per_s / world * T * conv_flops_per_frame(model) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                "serial_achieved": round(serial, 2),
+                "serial_frac": round(serial / MFMA_PEAK_TFLOPS, 4),
+                "serial_avg_launch_us": round(conv_ms * 1e3 / launches, 2),
             },
         }
         if use_oracle:
@@ -156,27 +184,92 @@ def main():
         dist.destroy_process_group()
 
 
+def launch_ranks(n: int) -> int:
+    """Start `n` ranks of this script (one per GPU) under torch.distributed.run and return their exit
+    code.  Runs before anything in this process has touched a GPU; the ranks are child processes."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
+    """The multi-rank plumbing of this script on CPU (gloo): same fences, same max-over-ranks timing,
+    same single JSON line from rank 0; the step is a stand-in matmul, so `value` measures nothing."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    B, Cn = args.clips, 100
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(B, 64, generator=g)
+    w = torch.randn(64, Cn, generator=torch.Generator().manual_seed(0))
+
+    def step():
+        y = x @ w
+        if world == 1:
+            return y
+        out = torch.empty(world * B, Cn)
+        dist.all_gather_into_tensor(out, y)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert out.shape == (B * world, Cn)
+    if rank == 0:
+        print(json.dumps({"metric": "clips/sec end-to-end (T=64, 224x224, bf16)", "value": None, "unit": "clips/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "CPU DRY RUN of the launcher and reporting path: stand-in step, "
+                                                 "no kernels, not a measurement",
+                                     "gathered_rows": int(out.shape[0])}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 CONV_KERNELS = ("stem_pool_kernel", "conv3x3_c64_kernel", "conv3x3_pp_kernel", "conv3x3_wide_kernel", "conv3x3_patch_kernel",
                 "gather_gemm_kernel")
 
 
-def pmc_traffic_per_launch(path=os.path.join(ROOT, "profiles", "r01_final_pmc_summary.csv")):
-    """HBM bytes per conv launch from the committed rocprofv3 PMC summary of this same command
-    ((2 * FETCH_SIZE + WRITE_SIZE) KiB per kernel, separate --pmc passes): counters cannot be read from
-    inside the timed run, so the figure is the last profiled one, or None when no summary is present."""
+def profiled_counters():
+    """Counter figures of the newest committed rocprofv3 PMC summary of this same command
+    (profiles/r*_counters.json, written by tools/pmc_summary.py from separate --pmc passes): HBM bytes
+    per chunk of frames with the gfx950 FETCH_SIZE correction applied, and the MFMA-busy ratio.
+    Counters cannot be read from inside the timed run, so these are the last profiled values; None
+    when no summary is present."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))
+    if not paths:
+        return None
     try:
-        tot, n = 0.0, 0
-        with open(path) as f:
-            for line in f:
-                parts = line.rstrip("\n").rsplit(",", 4)
-                if len(parts) == 5 and parts[1] == "HBM_BYTES_corrected" and any(k in parts[0] for k in CONV_KERNELS):
-                    tot += float(parts[3])
-                    n += int(parts[2])
-        if n:
-            return round(tot / n), f"HBM bytes per launch averaged over {n} profiled conv launches ({os.path.basename(path)})"
-    except OSError:
-        pass
-    return None, "no PMC summary found"
+        with open(paths[-1]) as f:
+            d = json.load(f)
+        d["note"] = (f"HBM bytes per conv launch = profiled (2*FETCH_SIZE + WRITE_SIZE) KiB of all kernels of a "
+                     f"{d.get('frames_per_chunk', '?')}-frame chunk x chunks per step / conv launches "
+                     f"({os.path.basename(paths[-1])})")
+        return d
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def time_conv_launches(model, clips, passes=3):
@@ -214,23 +307,49 @@ def cpu_baseline(oracle, model, T, S):
     the same clip through the GPU path gives the parity figures."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import asl_oracle as O
-    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-    torch.set_num_threads(threads)
+    logical = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    share = int(os.environ.get("OMP_NUM_THREADS", "0")) or usable      # the job's CPU share, when the box sets one
+    # thread counts tried: the job's share, and (when more CPUs are visible) twice that; best one is reported
+    tries = sorted({max(1, min(share, usable)), max(1, min(2 * share, usable))})
     clip = O.make_clips(1, T, S, seed=0)
+    reps, best = 3, None
     with torch.no_grad():
-        ref = oracle(clip)
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
+        for threads in tries:
+            torch.set_num_threads(threads)
             ref = oracle(clip)
-        dt = (time.perf_counter() - t0) / reps
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ref = oracle(clip)
+            dt = (time.perf_counter() - t0) / reps
+            if best is None or dt < best[0]:
+                best = (dt, threads)
+    dt, threads = best
     y = model(clip.cuda()).cpu()
     rel = float((y - ref).norm() / ref.norm())
     base = {"value": round(1.0 / dt, 3), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"1 clip x {T} frames {S}x{S} fp32, torch.nn CPU eager oracle, 1 warm-up + {reps} timed forwards"}
+            "host_logical_cpus": logical, "host_physical_cores": physical_cores(), "usable_cpus": usable,
+            "threads_tried": tries,
+            "sample": f"1 clip x {T} frames {S}x{S} fp32, torch.nn CPU eager oracle, 1 warm-up + {reps} timed forwards "
+                      f"per thread count, best reported"}
     parity = {"rel_l2_vs_cpu_oracle": rel, "argmax_identical": bool(torch.equal(y.argmax(1), ref.argmax(1))),
               "tolerance": 1e-3}
     return base, parity
+
+
+def physical_cores():
+    """Physical cores of the host from /proc/cpuinfo (distinct (physical id, core id) pairs), or None."""
+    try:
+        cores, phys = set(), None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    cores.add((phys, line.split(":")[1].strip()))
+        return len(cores) or None
+    except OSError:
+        return None
 
 
 if __name__ == "__main__":

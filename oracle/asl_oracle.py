@@ -271,7 +271,10 @@ class ClipModel(nn.Module):
     def forward(self, clips, keypoints=None):
         if self.name == "i3d":
             return self.backbone(clips.permute(0, 2, 1, 3, 4))
-        f = self.frame_features(clips)
+        return self.temporal_head(self.frame_features(clips), keypoints)
+
+    def temporal_head(self, f, keypoints=None):
+        """per-frame features [B,T,F] (+ keypoints) -> logits: everything after the backbone"""
         if self.name in ("tiny", "resnet18_mean"):
             return self.fc(f.mean(1))
         if self.name == "resnet50_bilstm":

@@ -40,3 +40,26 @@ def test_allgather_logits_world2(tmp_path):
 def test_gather_is_identity_without_process_group():
     x = torch.randn(3, 4)
     assert gather_logits(x) is x
+
+
+def test_bench_launches_its_own_ranks_for_gpus_2():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start the two ranks itself
+    (one JSON line from rank 0, exit code of the ranks); --cpu-dry-run swaps the kernels for a stand-in so
+    the launcher, rendezvous, fences and reporting run here without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--cpu-dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["gathered_rows"] == 16 and "DRY RUN" in d["config"]["workload"] and d["value"] is None
+    # ranks that fail (zero timed steps leave nothing to report) make the launcher's exit code non-zero
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "0", "--warmup", "0",
+                        "--cpu-dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

@@ -227,6 +227,24 @@ def test_clip_stream_equals_direct_classification(gpu):
     assert list(clipio.ClipStream(m)([])) == []
 
 
+def test_clip_stream_survives_shape_changes_while_batches_are_in_flight(gpu):
+    """batch shapes change in both directions mid-stream (buffers regrown while the previous batch's
+    kernels are still queued): every result still equals the direct classification of that batch"""
+    from video_asl_recognition_amd import clipio
+    _, m = _model("resnet18_mean")
+    shapes = [(3, 16, 60, 80), (1, 4, 48, 64), (4, 16, 72, 96), (1, 2, 60, 80), (3, 16, 60, 80), (2, 4, 48, 64)]
+    batches = [O.make_frames(b, t, h, w, seed=10 + i) for i, (b, t, h, w) in enumerate(shapes)]
+    direct = [m.classify_clip(b.cuda(), topk=3) for b in batches]
+    torch.cuda.synchronize()
+    cs = clipio.ClipStream(m, topk=3)
+    for _ in range(2):                                   # second pass reuses the grown buffers
+        streamed = list(cs(batches))
+        torch.cuda.synchronize()
+        assert len(streamed) == len(batches)
+        for k, ((i0, p0), (i1, p1)) in enumerate(zip(direct, streamed)):
+            assert torch.equal(i0, i1) and torch.equal(p0, p1), f"batch {k} {shapes[k]}"
+
+
 def test_sampled_video_and_keypoints_feed_the_two_stream_model(gpu):
     """sampler + keypoint normalisation produce tensors classify_clip accepts; result equals the oracle's
     on the same prepared inputs"""

@@ -257,12 +257,40 @@ def test_softmax_topk(gpu):
     torch.testing.assert_close(prob.cpu(), rp, rtol=1e-4, atol=1e-7)
 
 
-def test_lstm_bidir_layer(gpu):
+def test_softmax_topk_nan_and_inf_rows(gpu):
+    """NaN logits rank last, a row of -inf (or NaN) still yields k distinct in-range indices"""
+    from video_asl_recognition_amd import _lib as L
+    c, k = 300, 5
+    logits = torch.randn(4, c)
+    logits[0, 7] = float("nan")
+    logits[0, 9] = 9.0
+    logits[1] = float("-inf")
+    logits[2] = float("nan")
+    logits[3, :] = float("-inf")
+    logits[3, 250] = 1.0
+    idx = torch.full((4, k), -1, dtype=torch.int64, device="cuda")
+    prob = torch.empty(4, k, device="cuda")
+    ld = logits.cuda()
+    L.check(L.lib.asl_softmax_topk(_p(ld), 4, c, k, _p(idx), _p(prob), None))
+    torch.cuda.synchronize()
+    idx = idx.cpu()
+    assert bool(((idx >= 0) & (idx < c)).all())
+    for r in range(4):
+        assert len(set(idx[r].tolist())) == k
+    assert idx[0, 0].item() == 9 and 7 not in idx[0].tolist()
+    assert idx[1].tolist() == list(range(k)) and idx[2].tolist() == list(range(k))
+    assert idx[3].tolist() == [250, 0, 1, 2, 3]
+    assert abs(prob[3, 0].item() - 1.0) < 1e-6 and prob[3, 1].item() == 0.0
+
+
+# the unit-test shape, then the BiLSTM head's own: hidden 512 over 64 steps, an odd batch that needs two passes
+# of four rows, and the full per-GPU batch of 16 clips
+@pytest.mark.parametrize("B,T,I,H", [(3, 9, 64, 32), (5, 64, 256, 512), (16, 64, 128, 512)])
+def test_lstm_bidir_layer(gpu, B, T, I, H):
     """input-projection GEMM + fused recurrence against nn.LSTM (one bidirectional layer)"""
     from video_asl_recognition_amd import _lib as L
     from video_asl_recognition_amd.packing import pack_linear
     torch.manual_seed(11)
-    B, T, I, H = 3, 9, 64, 32
     lstm = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True, batch_first=True)
     with torch.no_grad():
         for p_ in lstm.parameters():
@@ -337,3 +365,40 @@ def test_attention_matches_sdpa_math(gpu, B, T):
     # P is rounded to bf16 before the PV product: 2^-9 relative per probability, averaged over T keys
     torch.testing.assert_close(got, ref, rtol=2e-2, atol=6e-3)
     assert float((got - ref).norm() / ref.norm()) < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# The temporal encoders at the sizes their configurations quote (64-step BiLSTM over 2048-d features at
+# 16 clips; 128-token transformer at 8 clips, 2000 classes), fed synthetic per-frame features so the CPU
+# oracle runs only its temporal part.  Tolerance: the path's 1e-3 relative L2 on logits, arg-max identical.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,B,T", [("resnet50_bilstm", 16, 64), ("resnet50_bilstm", 5, 64),
+                                      ("twostream_transformer", 8, 128), ("twostream_transformer", 3, 50)])
+def test_temporal_head_at_config_size(gpu, name, B, T):
+    import ctypes
+    from video_asl_recognition_amd import AslClipModel
+    om = O.build(name, seed=3)
+    m = AslClipModel(name)
+    m.load_state_dict(om.state_dict())
+    spec = m.spec
+    Fd = spec.feat_dim
+    g = torch.Generator().manual_seed(77)
+    # what a global average pool of post-ReLU maps looks like: non-negative, O(1)
+    feats = (torch.randn(B, T, Fd, generator=g).abs() * 0.6).to(torch.bfloat16).float()
+    kp = O.make_keypoints(B, T, seed=5) if spec.keypoints else None
+    with torch.no_grad():
+        ref = om.temporal_head(feats, kp)
+    fd = feats.reshape(B * T, Fd).cuda()
+    if spec.temporal == "bilstm":
+        hi = fd.to(torch.bfloat16)
+        fb = torch.cat([hi, (fd - hi.float()).to(torch.bfloat16)], 1).contiguous()
+    else:
+        fb = torch.zeros(B * T, Fd + spec.kp_hidden, dtype=torch.bfloat16, device="cuda")
+        fb[:, :Fd] = fd.to(torch.bfloat16)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y = m._temporal(fd, fb, fb.shape[1], B, T, kp, stream)
+    torch.cuda.synchronize()
+    y = y.cpu()
+    rel = float((y - ref).norm() / ref.norm())
+    assert rel <= 1e-3, f"{name} B={B} T={T}: rel-L2 {rel:.3e}"
+    assert torch.equal(y.argmax(1), ref.argmax(1))

@@ -188,40 +188,53 @@ class ClipStream:
     def __init__(self, model, topk: int = 5):
         self.model, self.topk = model, int(topk)
         self._copy = torch.cuda.Stream(device=model.device)
+        # flat byte buffers, grown to the largest batch seen and viewed at each batch's shape
         self._pin: List[Optional[torch.Tensor]] = [None, None]
         self._dev: List[Optional[torch.Tensor]] = [None, None]
         self._free: List[Optional[torch.cuda.Event]] = [None, None]   # device buffer no longer read
 
-    def _stage(self, slot: int, batch: torch.Tensor) -> torch.cuda.Event:
+    def _stage(self, slot: int, batch: torch.Tensor):
+        """Starts the transfer of `batch` into device buffer `slot`; returns (event, device view)."""
         if batch.dtype != torch.uint8 or batch.dim() != 5:
             raise ValueError("batches must be uint8 [B,T,H0,W0,3]")
-        if self._pin[slot] is None or self._pin[slot].shape != batch.shape:
-            self._pin[slot] = torch.empty(batch.shape, dtype=torch.uint8, pin_memory=True)
-            self._dev[slot] = torch.empty(batch.shape, dtype=torch.uint8, device=self.model.device)
-            self._free[slot] = None
+        nbytes = batch.numel()
+        # The previous user of this slot must have finished reading before the buffer is overwritten -- or
+        # released: a dropped buffer goes back to the allocator and may be handed out again at once.
         if self._free[slot] is not None:
-            self._free[slot].synchronize()        # the previous user of this slot has finished reading it
-        src = batch
-        if not batch.is_pinned():                 # pageable memory: stage it (a pinned batch is transferred as it is
-            self._pin[slot].copy_(batch)          # and must stay untouched until its result has been yielded)
-            src = self._pin[slot]
+            self._free[slot].synchronize()
+            self._free[slot] = None
+        if self._dev[slot] is None or self._dev[slot].numel() < nbytes:
+            self._dev[slot] = None
+            # Allocated with the copy stream current: the caching allocator keeps a pool per stream, so this
+            # block cannot be one that classify_clip's kernels, still queued on the compute streams, have
+            # released on the host but not finished using, and the copy below needs no ordering against them.
+            with torch.cuda.stream(self._copy):
+                self._dev[slot] = torch.empty(nbytes, dtype=torch.uint8, device=self.model.device)
+        src = batch.contiguous()
+        if not src.is_pinned():                   # pageable memory: stage it (a pinned batch is transferred as it is
+            if self._pin[slot] is None or self._pin[slot].numel() < nbytes:   # and must stay untouched until its
+                self._pin[slot] = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)   # result has been yielded)
+            pin = self._pin[slot][:nbytes].view(batch.shape)
+            pin.copy_(src)
+            src = pin
+        dev = self._dev[slot][:nbytes].view(batch.shape)
         with torch.cuda.stream(self._copy):
-            self._dev[slot].copy_(src, non_blocking=True)
+            dev.copy_(src, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._copy)
-        return ev
+        return ev, dev
 
     def __call__(self, batches: Iterable[torch.Tensor]) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         it = iter(batches)
         try:
-            ready = self._stage(0, next(it))
+            ready, dev = self._stage(0, next(it))
         except StopIteration:
             return
         slot = 0
         nxt = next(it, None)
         while True:
             torch.cuda.current_stream().wait_event(ready)
-            out = self.model.classify_clip(self._dev[slot], topk=self.topk)      # asynchronous launches
+            out = self.model.classify_clip(dev, topk=self.topk)      # asynchronous launches
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream())
             self._free[slot] = done
@@ -229,7 +242,7 @@ class ClipStream:
                 yield out
                 return
             # host copy into pinned memory and the H2D transfer run while the GPU works on this batch
-            ready = self._stage(slot ^ 1, nxt)
+            ready, dev = self._stage(slot ^ 1, nxt)
             slot ^= 1
             nxt = next(it, None)
             yield out

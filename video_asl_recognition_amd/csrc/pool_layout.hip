@@ -351,8 +351,13 @@ __global__ __launch_bounds__(256) void softmax_topk_kernel(const float* __restri
     __shared__ int wredi[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* lr = logits + (long long)row * c;
+    // NaN logits rank last: they are staged as -inf (fmaxf already ignores them for the row maximum)
     float mx = -INFINITY;
-    for (int i = tid; i < c; i += 256) { v[i] = lr[i]; mx = fmaxf(mx, lr[i]); }
+    for (int i = tid; i < c; i += 256) {
+        const float x = lr[i];
+        v[i] = x == x ? x : -INFINITY;
+        mx = fmaxf(mx, x);
+    }
     mx = wave_max(mx);
     if (lane == 0) wred[wv] = mx;
     __syncthreads();
@@ -365,25 +370,35 @@ __global__ __launch_bounds__(256) void softmax_topk_kernel(const float* __restri
     __syncthreads();
     sum = (wred[0] + wred[1]) + (wred[2] + wred[3]);
     __syncthreads();
+    // k rounds of arg-max.  A picked entry is marked NaN (never a candidate again); among candidates an
+    // index always wins over "none yet" (kNone), so rows of -inf still yield k distinct valid indices.
+    constexpr int kNone = 0x7fffffff;
     for (int r = 0; r < k; ++r) {
         float best = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int i = tid; i < c; i += 256)
-            if (v[i] > best) { best = v[i]; bi = i; }     // ascending i: first maximum wins
+        int bi = kNone;
+        for (int i = tid; i < c; i += 256) {
+            const float x = v[i];
+            if (x == x && (bi == kNone || x > best)) { best = x; bi = i; }     // ascending i: first maximum wins
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ob = __shfl_xor(best, o, 64);
             const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            if (oi != kNone && (bi == kNone || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
         }
         if (lane == 0) { wred[wv] = best; wredi[wv] = bi; }
         __syncthreads();
         if (tid == 0) {
             for (int q = 1; q < 4; ++q)
-                if (wred[q] > best || (wred[q] == best && wredi[q] < bi)) { best = wred[q]; bi = wredi[q]; }
-            idx[(long long)row * k + r] = bi;
-            prob[(long long)row * k + r] = expf(best - mx) / sum;
-            v[bi] = -INFINITY;
+                if (wredi[q] != kNone && (bi == kNone || wred[q] > best || (wred[q] == best && wredi[q] < bi))) {
+                    best = wred[q];
+                    bi = wredi[q];
+                }
+            if (bi < c) {                      // always true for k <= c; never index LDS with a sentinel
+                idx[(long long)row * k + r] = bi;
+                prob[(long long)row * k + r] = expf(best - mx) / sum;
+                v[bi] = __builtin_nanf("");
+            }
         }
         __syncthreads();
     }
