@@ -10,7 +10,9 @@
  *
  * Conventions
  *   - Every pointer is a DEVICE pointer owned by the caller.  The library never
- *     allocates, frees or retains memory, and keeps no mutable global state.
+ *     allocates, frees or retains caller memory.  Its only mutable state is the per-device
+ *     address of the built-in scratch array of asl_lstm_bidir_layer_static (looked up once per
+ *     device); kernel selection depends on the arguments alone.
  *   - Every launcher is asynchronous on the caller-supplied stream and returns
  *     ASL_OK (0) or a negative ASL_E* code / positive hipError_t.  Geometry that a
  *     kernel cannot execute safely is rejected with ASL_EINVAL before any launch.
@@ -36,7 +38,8 @@ typedef struct ihipStream_t* asl_stream_t; /* == hipStream_t */
 enum {
     ASL_OK = 0,
     ASL_EINVAL = -1,   /* shape / alignment / bounds violation, nothing launched */
-    ASL_ENOTSUP = -2   /* valid request that no compiled kernel variant covers   */
+    ASL_ENOTSUP = -2,  /* valid request that no compiled kernel variant covers   */
+    ASL_ETOOBIG = -3   /* request exceeds a fixed capacity of the library (see the entry point) */
 };
 
 int asl_version(void);
@@ -239,6 +242,23 @@ typedef struct asl_lstm_params {
 
 int asl_lstm_bidir_layer(const asl_lstm_params* p, const float* gx, const void* w_hh, void* y_bf16,
                          float* ysum, float* state, asl_stream_t stream);
+
+/* asl_lstm_bidir_layer without the caller's `state` scratch.  This entry point has no counterpart
+ * in the reference (nor a torch operator it stands in for beyond nn.LSTM above): it exists for
+ * callers that cannot allocate device memory around the call -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  The recurrent state lives in a device array built
+ * into the library (ASL_LSTM_STATIC_STATE_FLOATS floats = 1.5 MiB, held by every GPU the library is
+ * used on until the process ends); the call allocates nothing and frees nothing.
+ *   - 6 * batch * hidden must not exceed ASL_LSTM_STATIC_STATE_FLOATS (e.g. batch 128 at hidden 512,
+ *     batch 64 at hidden 1024); larger requests return ASL_ETOOBIG and launch nothing.
+ *   - The array's address is looked up on the first call made with a given device current
+ *     (hipGetSymbolAddress); make that first call outside graph capture.
+ *   - All calls on one GPU share the array: it is zeroed at the start of every call, and two calls
+ *     that overlap on one GPU (different streams, or threads) race.  Serialize them.
+ * Arguments, outputs and arithmetic are otherwise those of asl_lstm_bidir_layer (bit-identical). */
+#define ASL_LSTM_STATIC_STATE_FLOATS (6 * 64 * 1024)
+int asl_lstm_bidir_layer_static(const asl_lstm_params* p, const float* gx, const void* w_hh,
+                                void* y_bf16, float* ysum, asl_stream_t stream);
 
 /* nn.LayerNorm(d) over fp32 rows: y = (x - mean) / sqrt(var + eps) * gamma + beta, written as bf16
  * (row pitch ld_bf16) and/or fp32; at least one output.  d % 4 == 0. */

@@ -70,6 +70,20 @@ def test_bad_geometry_is_rejected_without_launch():
         L.check(L.ASL_EINVAL, "probe")
 
 
+def test_static_lstm_rejects_requests_beyond_its_built_in_state():
+    """the allocation-free LSTM entry point refuses 6*batch*hidden floats above its array before any HIP call"""
+    from video_asl_recognition_amd import _lib as L
+    fake = C.c_void_p(0x1000)
+    p = L.LstmParams(batch=129, t=4, hidden=512, ld_gx=4096, ld_y=2048, split_y=1, ysum_scale=0.25)
+    assert 6 * 129 * 512 > L.LSTM_STATIC_STATE_FLOATS
+    assert L.lib.asl_lstm_bidir_layer_static(C.byref(p), fake, fake, fake, None, None) == L.ASL_ETOOBIG
+    assert "capacity" in L.strerror(L.ASL_ETOOBIG)
+    p.batch = 0
+    assert L.lib.asl_lstm_bidir_layer_static(C.byref(p), fake, fake, fake, None, None) == L.ASL_EINVAL
+    hdr = open(HEADER).read()
+    assert re.search(r"#define\s+ASL_LSTM_STATIC_STATE_FLOATS\s+\(6 \* 64 \* 1024\)", hdr)
+
+
 def test_model_refuses_to_run_without_gpu():
     import torch
     if torch.cuda.is_available():

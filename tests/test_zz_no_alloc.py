@@ -1,0 +1,68 @@
+"""GPU: asl_lstm_bidir_layer_static (state in the library's built-in device array, no allocation)
+against asl_lstm_bidir_layer (state in caller scratch) through the C ABI.  The two share every kernel
+and the same launch order, so outputs must be bit-identical.  Two calls in a row, the second on a
+smaller input, so stale contents of the shared array from the first call would show; then the
+capacity limit."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _inputs(B, T, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    gx = (torch.randn(B * T, 8 * H, generator=g) * 0.8).cuda()
+    w_hh = (torch.randn(2, 4 * H, H, generator=g) * (1.0 / H ** 0.5)).to(torch.bfloat16).cuda()
+    return gx, w_hh
+
+
+def _run(L, B, T, H, gx, w_hh, static):
+    # outputs poisoned, so a skipped write shows
+    y = torch.full((B * T, 4 * H), 7.0, dtype=torch.bfloat16, device="cuda")
+    ysum = torch.full((B, 2 * H), 7.0, device="cuda")
+    p = L.LstmParams(batch=B, t=T, hidden=H, ld_gx=8 * H, ld_y=4 * H, split_y=1, ysum_scale=1.0 / T)
+    if static:
+        L.check(L.lib.asl_lstm_bidir_layer_static(C.byref(p), _p(gx), _p(w_hh), _p(y), _p(ysum), None), "lstm static")
+    else:
+        state = torch.full((6 * B * H,), 3.0, device="cuda")
+        L.check(L.lib.asl_lstm_bidir_layer(C.byref(p), _p(gx), _p(w_hh), _p(y), _p(ysum), _p(state), None), "lstm")
+    torch.cuda.synchronize()
+    return y.cpu(), ysum.cpu()
+
+
+def test_static_state_lstm_equals_caller_state_lstm(gpu):
+    from video_asl_recognition_amd import _lib as L
+    # first call: the BiLSTM head's own shape (odd batch, two passes of four rows); second: smaller in
+    # every dimension, so it reuses a prefix of the array the first call left full of non-zero state
+    for B, T, H, seed in ((5, 64, 512, 21), (2, 9, 32, 22)):
+        gx, w_hh = _inputs(B, T, H, seed)
+        y_ref, s_ref = _run(L, B, T, H, gx, w_hh, static=False)
+        y, s = _run(L, B, T, H, gx, w_hh, static=True)
+        assert torch.isfinite(s_ref).all() and float(s_ref.abs().max()) > 0
+        assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), f"y differs at B={B},T={T},H={H}"
+        assert torch.equal(s, s_ref), f"ysum differs at B={B},T={T},H={H}"
+
+
+def test_static_state_lstm_rejects_oversize(gpu):
+    from video_asl_recognition_amd import _lib as L
+    B, T, H = 129, 1, 512                      # 6*129*512 floats: one batch row over the array's size
+    assert 6 * B * H > L.LSTM_STATIC_STATE_FLOATS >= 6 * (B - 1) * H
+    gx, w_hh = _inputs(B, T, H, 23)
+    y = torch.full((B * T, 4 * H), 7.0, dtype=torch.bfloat16, device="cuda")
+    p = L.LstmParams(batch=B, t=T, hidden=H, ld_gx=8 * H, ld_y=4 * H, split_y=1, ysum_scale=1.0)
+    rc = L.lib.asl_lstm_bidir_layer_static(C.byref(p), _p(gx), _p(w_hh), _p(y), None, None)
+    assert rc == L.ASL_ETOOBIG and "capacity" in L.strerror(rc)
+    torch.cuda.synchronize()
+    assert bool((y == 7.0).all()), "an oversize request must launch nothing"
+    # the largest request that fits still runs and matches
+    B = 128
+    gx, w_hh = _inputs(B, T, H, 24)
+    y_ref, _ = _run(L, B, T, H, gx, w_hh, static=False)
+    y_st, _ = _run(L, B, T, H, gx, w_hh, static=True)
+    assert torch.equal(y_st.view(torch.int16), y_ref.view(torch.int16))

@@ -11,7 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libaslhip.so")
 
-ASL_OK, ASL_EINVAL, ASL_ENOTSUP = 0, -1, -2
+ASL_OK, ASL_EINVAL, ASL_ENOTSUP, ASL_ETOOBIG = 0, -1, -2, -3
+LSTM_STATIC_STATE_FLOATS = 6 * 64 * 1024
 
 
 class Geom(C.Structure):
@@ -94,6 +95,7 @@ _PROTOS = {
     "asl_head_f32": ([_P, _I, _I, _P, _P, _I, _P, _P], C.c_int),
     "asl_softmax_topk": ([_P, _I, _I, _I, _P, _P, _P], C.c_int),
     "asl_lstm_bidir_layer": ([C.POINTER(LstmParams), _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_lstm_bidir_layer_static": ([C.POINTER(LstmParams), _P, _P, _P, _P, _P], C.c_int),
     "asl_layernorm_f32": ([_P, _I, _I, _P, _P, C.c_float, _P, _I, _P, _P], C.c_int),
     "asl_add_rows_f32": ([_P, _I, _I, _P, _I, _P, _P, _I, _P], C.c_int),
     "asl_cast_pad_bf16": ([_P, _I, _I, _P, _I, _P], C.c_int),

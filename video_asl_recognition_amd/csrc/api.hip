@@ -5,13 +5,14 @@
 
 #include "asl_hip.h"
 
-extern "C" int asl_version(void) { return 100; }
+extern "C" int asl_version(void) { return 101; }
 
 extern "C" const char* asl_strerror(int rc) {
     switch (rc) {
         case ASL_OK: return "ok";
         case ASL_EINVAL: return "asl: invalid argument (shape, alignment or bounds)";
         case ASL_ENOTSUP: return "asl: no kernel variant for this request";
+        case ASL_ETOOBIG: return "asl: request exceeds the library's built-in scratch capacity";
         default: return rc > 0 ? hipGetErrorString((hipError_t)rc) : "asl: unknown error";
     }
 }

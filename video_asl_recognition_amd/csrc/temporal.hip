@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "asl_hip.h"
 #include "common.h"
 
@@ -326,13 +328,13 @@ int grid_rows(long long total) {
 }  // namespace asl_detail
 using namespace asl_detail;
 
-extern "C" int asl_lstm_bidir_layer(const asl_lstm_params* p, const float* gx, const void* w_hh, void* y_bf16,
-                                    float* ysum, float* state, asl_stream_t stream) {
+// Shared body of the two LSTM entry points: validates, zeroes the state, issues one launch per step.
+static int lstm_run(const asl_lstm_params* p, const float* gx, const void* w_hh, void* y_bf16, float* ysum,
+                    float* state, hipStream_t s) {
     if (!p || !gx || !w_hh || !y_bf16 || !state) return ASL_EINVAL;
     if (p->batch <= 0 || p->t <= 0 || p->hidden <= 0 || (p->hidden & 7)) return ASL_EINVAL;
     if (p->ld_gx < 8 * p->hidden || p->ld_y < (p->split_y ? 4 : 2) * p->hidden) return ASL_EINVAL;
     if (((uintptr_t)w_hh & 15) || ((uintptr_t)state & 15)) return ASL_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
     const long long n = 2LL * p->batch * p->hidden;           // elements of one [2][B][H] state array
     // state = h ping | h pong | c ; zero initial state, and the running sum if requested
     hipError_t e = hipMemsetAsync(state, 0, (size_t)(3 * n) * sizeof(float), s);
@@ -353,6 +355,55 @@ extern "C" int asl_lstm_bidir_layer(const asl_lstm_params* p, const float* gx, c
         hipLaunchKernelGGL(lstm_step_kernel, dim3(blocks), dim3(256), 0, s, a);
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int asl_lstm_bidir_layer(const asl_lstm_params* p, const float* gx, const void* w_hh, void* y_bf16,
+                                    float* ysum, float* state, asl_stream_t stream) {
+    return lstm_run(p, gx, w_hh, y_bf16, ysum, state, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Allocation-free variant: the recurrent state (h ping | h pong | c) lives in a device array that is
+// part of the library's code object, so the caller brings no scratch and nothing here allocates.
+// Every GPU the library runs on holds its own copy of the array (1.5 MiB) at its own address; the
+// address is looked up once per device, on the first call made with that device current, and only
+// that looked-up pointer is ever handed to hipMemsetAsync or a kernel -- the array's name in host
+// code is not a device address.
+// ---------------------------------------------------------------------------------------------
+static __device__ __align__(256) float scratch[ASL_LSTM_STATIC_STATE_FLOATS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+float* g_scratch_ptr[kMaxDevices];        // per device, null until that device's first call
+
+int scratch_of_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= kMaxDevices) return ASL_EINVAL;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* ptr = nullptr;
+        e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!ptr) return ASL_EINVAL;
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return ASL_OK;
+}
+}  // namespace
+
+extern "C" int asl_lstm_bidir_layer_static(const asl_lstm_params* p, const float* gx, const void* w_hh,
+                                           void* y_bf16, float* ysum, asl_stream_t stream) {
+    if (!p) return ASL_EINVAL;
+    if (p->batch <= 0 || p->hidden <= 0) return ASL_EINVAL;
+    if (6LL * p->batch * p->hidden > (long long)ASL_LSTM_STATIC_STATE_FLOATS) return ASL_ETOOBIG;
+    float* state = nullptr;
+    const int rc = scratch_of_current_device(&state);
+    if (rc != ASL_OK) return rc;
+    return lstm_run(p, gx, w_hh, y_bf16, ysum, state, (hipStream_t)stream);
 }
 
 extern "C" int asl_layernorm_f32(const float* x, int rows, int d, const float* gamma, const float* beta, float eps,
