@@ -273,28 +273,39 @@ def profiled_counters():
 
 
 def time_conv_launches(model, clips, passes=3):
-    """Sum of the gather-GEMM launch durations of one step (ms) and their count, from events
-    recorded around each conv launch on the launch stream."""
+    """Sum of the conv launch durations of one step (ms) and their count: every op of the plan issued
+    alone on the current stream, conv launches bracketed by events on that stream."""
     import ctypes as C
-    n_total = clips.shape[0] * clips.shape[1]
+    from video_asl_recognition_amd import _lib as L
+    B, T, _, S, _ = clips.shape
+    n_total = B * T
     plan = model._get_plans(min(n_total, model.frames_per_chunk), 1)[0]
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    conv_ops = [op for op in plan["ops"] if op.__name__ == "run"]
+    sarr = (C.c_void_p * 1)(torch.cuda.current_stream().cuda_stream)
+    one = (L.Op * 1)()
+    esz = clips.element_size()
     best = None
     for _ in range(passes):
         total_ms, launches = 0.0, 0
         for c0 in range(0, n_total, plan["nmax"]):
             n = min(plan["nmax"], n_total - c0)
+            one[0] = L.make_op(L.OP_PACK_CLIPS, None, [clips.data_ptr() + c0 * 3 * S * S * esz, plan["x0"].data_ptr()],
+                               [int(clips.dtype == torch.float32), n, S, plan["in_halo"]])
+            L.run_ops(one, 1, sarr, 1, "pack")
             evs = []
-            for op in plan["ops"]:
-                if op in conv_ops:
+            for rec in plan["ops"]:
+                if rec["params"] is not None:
+                    rec["params"].n = n
+                one[0] = rec["op"]
+                if rec["n_slot"] is not None:
+                    one[0].i[rec["n_slot"]] = n
+                if rec["conv"]:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    op(n, stream)
+                    L.run_ops(one, 1, sarr, 1, "conv")
                     e1.record()
                     evs.append((e0, e1))
                 else:
-                    op(n, stream)
+                    L.run_ops(one, 1, sarr, 1, "op")
             torch.cuda.synchronize()
             total_ms += sum(a.elapsed_time(b) for a, b in evs)
             launches += len(evs)

@@ -67,6 +67,19 @@ typedef struct asl_geom {
  *   scale  fp32 [cout] or NULL (1.0);  bias fp32 [cout] or NULL (0.0)
  *   res    residual (bf16, or fp32 if res_f32) or NULL;  y bf16 (out_f32 == 0) or fp32 (out_f32 == 1)
  *   *_elems  allocation sizes in elements, used to reject out-of-bounds geometry.       */
+/* Kernel variants of the conv / GEMM entry points.  ASL_CONV_AUTO (0) lets the library choose from the
+ * request's shape alone; any other value forces that kernel and returns ASL_ENOTSUP when the request does not
+ * fit it (parity tests and A/B timing use this; production callers leave the field 0). */
+enum {
+    ASL_CONV_AUTO = 0,
+    ASL_CONV_GATHER = 1,    /* generic 4-wave gather-GEMM (any shape)                                  */
+    ASL_CONV_PATCH = 2,     /* 3x3/s1/p1, LDS-resident patch, 256 x 64 tile                            */
+    ASL_CONV_PP = 3,        /* 3x3/s1/p1, C >= 128, N % 128 == 0: 8-wave 256 x 128 tile, two per CU    */
+    ASL_CONV_PP_BIG = 4,    /* the same kernel with a 512 x 128 tile, one per CU                       */
+    ASL_CONV_WIDE = 5,      /* 3x3/s1/p1, C % 64 == 0, C >= 128: 16-wave 512 x 128 tile                */
+    ASL_CONV_C64 = 6        /* 3x3/s1/p1, 64 -> 64 channels: persistent, weights resident in LDS       */
+};
+
 typedef struct asl_gemm_params {
     int32_t nb, od, oh, ow;          /* output grid; M = nb*od*oh*ow            */
     int32_t cout;
@@ -79,6 +92,8 @@ typedef struct asl_gemm_params {
     int32_t res_f32;
     int32_t w_rows;
     int64_t x_elems, y_elems, res_elems;
+    int32_t variant;                 /* ASL_CONV_*                              */
+    int32_t reserved;                /* must be 0                               */
 } asl_gemm_params;
 
 int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, const void* w,
@@ -98,6 +113,7 @@ typedef struct asl_conv2d_params {
     int32_t res_halo, res_ctot, res_coff;
     int32_t relu;
     int32_t w_rows;
+    int32_t variant;                 /* ASL_CONV_*; 0 = chosen by the library  */
 } asl_conv2d_params;
 
 int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, const void* w,
@@ -281,6 +297,50 @@ typedef struct asl_attn_params {
 } asl_attn_params;
 
 int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Batched issue
+ * ---------------------------------------------------------------------------------- */
+
+/* One launch of one of the entry points above, as data.  asl_run_ops issues `count` of them in array order,
+ * each on streams[op.stream], with the arguments, validation and return codes of the entry point the kind
+ * names -- it exists so that a host written in an interpreted language pays one foreign call per batch of
+ * launches instead of one per launch (a ResNet-18 chunk is 23 launches).  Nothing is retained: the array,
+ * the params structs it points to and the streams array are read during the call only.
+ *
+ *   kind                 params                  ptr[]                                   i[] / f[]
+ *   ASL_OP_CONV2D        asl_conv2d_params*      x, w, scale, bias, res, y
+ *   ASL_OP_STEM_CONV     asl_stem_params*        x, w, scale, bias, y
+ *   ASL_OP_STEM_POOL     asl_stem_pool_params*   x, w, scale, bias, y
+ *   ASL_OP_CONV3D        asl_conv3d_params*      x, w, scale, bias, y
+ *   ASL_OP_LINEAR        asl_linear_params*      x, w, scale, bias, res, y
+ *   ASL_OP_MAXPOOL3D     asl_pool3d_params*      x, y
+ *   ASL_OP_MAXPOOL       NULL                    x, y                                    n, h, w, c, in_halo, out_halo
+ *   ASL_OP_AVGPOOL       NULL                    x, y_f32, y_bf16                        n, h, w, c, halo, ld_bf16, lo_off
+ *   ASL_OP_PACK_CLIPS    NULL                    clips, y                                in_f32, n, s, halo
+ *   ASL_OP_PREPROCESS    NULL                    frames, y, clips_f32                    n, h0, w0, s, halo / mean[3], std[3]
+ *   ASL_OP_MEAN_T        NULL                    x, y                                    rows, t, c
+ *   ASL_OP_HEAD          NULL                    x, w, b, y                              m, f, c
+ *
+ * Returns ASL_OK, or the first failing op's return code with its index in *failed (if failed != NULL); ops
+ * before it have been issued, ops after it have not.  ASL_EINVAL for an unknown kind, a stream index outside
+ * [0, nstreams) or a missing params struct. */
+enum {
+    ASL_OP_CONV2D = 1, ASL_OP_STEM_CONV = 2, ASL_OP_STEM_POOL = 3, ASL_OP_CONV3D = 4, ASL_OP_LINEAR = 5,
+    ASL_OP_MAXPOOL3D = 6, ASL_OP_MAXPOOL = 7, ASL_OP_AVGPOOL = 8, ASL_OP_PACK_CLIPS = 9, ASL_OP_PREPROCESS = 10,
+    ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12
+};
+
+typedef struct asl_op {
+    int32_t kind;
+    int32_t stream;
+    const void* params;
+    void* ptr[6];
+    int32_t i[8];
+    float f[6];
+} asl_op;
+
+int asl_run_ops(const asl_op* ops, int count, const asl_stream_t* streams, int nstreams, int* failed);
 
 #ifdef __cplusplus
 }

@@ -35,13 +35,13 @@ def test_version_and_strerror():
 def test_struct_sizes_match_header_layout():
     from video_asl_recognition_amd import _lib as L
     assert C.sizeof(L.Geom) == 24
-    assert C.sizeof(L.Conv2dParams) == 18 * 4
+    assert C.sizeof(L.Conv2dParams) == 19 * 4
     assert C.sizeof(L.StemParams) == 12 * 4
     assert C.sizeof(L.Conv3dParams) == 21 * 4
     assert C.sizeof(L.LinearParams) == 10 * 4
     assert C.sizeof(L.LstmParams) == 7 * 4 and C.sizeof(L.AttnParams) == 6 * 4
     assert C.sizeof(L.Pool3dParams) == 18 * 4
-    assert C.sizeof(L.GemmParams) == 12 * 4 + 3 * 24 + 4 * 4 + 3 * 8
+    assert C.sizeof(L.GemmParams) == 12 * 4 + 3 * 24 + 4 * 4 + 3 * 8 + 2 * 4
 
 
 def test_bad_geometry_is_rejected_without_launch():

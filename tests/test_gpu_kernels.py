@@ -65,10 +65,10 @@ def test_conv2d_bn_res_relu(gpu, n, h, w, cin, cout, k, stride, pad, res, relu):
     _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu)
 
 
-# Every 3x3 / stride 1 kernel variant on the shapes it takes (the library reads these switches per call):
-# the 16-wave 512 x 128 kernel from 128 channels up, the 8-wave 256 x 128 one alone, and its 512-pixel form.
-KERNEL_SWITCHES = [{"ASL_WIDE_MIN_C": "128", "ASL_WIDE_ANY_GRID": "1"}, {"ASL_NO_WIDE_CONV": "1"},
-                   {"ASL_NO_WIDE_CONV": "1", "ASL_PP_BIG": "1"}]
+# Every 3x3 / stride 1 kernel variant on the shapes it takes, forced through the params' `variant` field:
+# the 16-wave 512 x 128 kernel, the 8-wave 256 x 128 one, its 512-pixel form, the 256 x 64 patch kernel and
+# the generic gather-GEMM.
+KERNEL_VARIANTS = ["CONV_WIDE", "CONV_PP", "CONV_PP_BIG", "CONV_PATCH", "CONV_GATHER"]
 LARGE_TILE_CASES = [
     (9, 28, 28, 128, 128, 3, 1, 1, True, True),      # tiles straddle rows and images, partial last tile
     (20, 28, 28, 128, 256, 3, 1, 1, False, False),   # two channel tiles, no residual, no ReLU
@@ -81,17 +81,23 @@ LARGE_TILE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("switches", KERNEL_SWITCHES, ids=["wide16", "twin", "big"])
+@pytest.mark.parametrize("variant", KERNEL_VARIANTS)
 @pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,res,relu", LARGE_TILE_CASES)
-def test_large_tile_conv_variants(gpu, monkeypatch, switches, n, h, w, cin, cout, k, stride, pad, res, relu):
-    for name in ("ASL_WIDE_MIN_C", "ASL_WIDE_ANY_GRID", "ASL_NO_WIDE_CONV", "ASL_PP_BIG"):
-        monkeypatch.delenv(name, raising=False)
-    for name, v in switches.items():
-        monkeypatch.setenv(name, v)
-    _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu)
+def test_large_tile_conv_variants(gpu, variant, n, h, w, cin, cout, k, stride, pad, res, relu):
+    from video_asl_recognition_amd import _lib as L
+    if variant == "CONV_WIDE" and cin % 64:
+        pytest.skip("the 16-wave kernel takes whole 64-channel chunks")
+    _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu, variant=getattr(L, variant))
 
 
-def _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu):
+def test_forced_variant_that_does_not_fit_is_refused(gpu):
+    from video_asl_recognition_amd import _lib as L
+    for variant in (L.CONV_C64, L.CONV_PP, L.CONV_WIDE):      # a 1x1 conv fits none of the 3x3 kernels
+        with pytest.raises(RuntimeError, match="no kernel variant"):
+            _run_conv_case(1, 8, 8, 64, 64, 1, 1, 0, False, False, variant=variant)
+
+
+def _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu, variant=0):
     from video_asl_recognition_amd import _lib as L
     from video_asl_recognition_amd.packing import pack_conv
     g = torch.Generator().manual_seed(h * 131 + cin)
@@ -112,7 +118,7 @@ def _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu):
     yd = torch.zeros(n, oh + 2, ow + 2, cout, dtype=torch.bfloat16, device="cuda")
     p = L.Conv2dParams(n=n, h=h, w=w, cin=cin, in_halo=1, cout=cout, kh=k, kw=k, stride=stride, pad=pad, out_halo=1,
                        out_ctot=cout, out_coff=0, res_halo=1, res_ctot=cout, res_coff=0, relu=int(relu),
-                       w_rows=pc.w_rows)
+                       w_rows=pc.w_rows, variant=variant)
     L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(p), _p(xd), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(rd), _p(yd), None))
     torch.cuda.synchronize()
     assert yd[:, 0].abs().sum() == 0 and yd[:, :, 0].abs().sum() == 0, "halo was written"

@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libaslhip.so")
 
 ASL_OK, ASL_EINVAL, ASL_ENOTSUP, ASL_ETOOBIG = 0, -1, -2, -3
+# kernel variants of asl_conv2d_nhwc_bf16 / asl_gather_gemm_bf16 (0 = the library chooses)
+CONV_AUTO, CONV_GATHER, CONV_PATCH, CONV_PP, CONV_PP_BIG, CONV_WIDE, CONV_C64 = range(7)
 LSTM_STATIC_STATE_FLOATS = 6 * 64 * 1024
 
 
@@ -25,13 +27,14 @@ class GemmParams(C.Structure):
                 ("ck", C.c_int32), ("tap_sd", C.c_int32), ("tap_sh", C.c_int32), ("tap_sw", C.c_int32),
                 ("in_", Geom), ("out", Geom), ("res", Geom),
                 ("relu", C.c_int32), ("out_f32", C.c_int32), ("res_f32", C.c_int32), ("w_rows", C.c_int32),
-                ("x_elems", C.c_int64), ("y_elems", C.c_int64), ("res_elems", C.c_int64)]
+                ("x_elems", C.c_int64), ("y_elems", C.c_int64), ("res_elems", C.c_int64),
+                ("variant", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Conv2dParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "h", "w", "cin", "in_halo", "cout", "kh", "kw", "stride", "pad",
-        "out_halo", "out_ctot", "out_coff", "res_halo", "res_ctot", "res_coff", "relu", "w_rows")]
+        "out_halo", "out_ctot", "out_coff", "res_halo", "res_ctot", "res_coff", "relu", "w_rows", "variant")]
 
 
 class StemParams(C.Structure):
@@ -61,6 +64,16 @@ class Pool3dParams(C.Structure):
 
 class LstmParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("batch", "t", "hidden", "ld_gx", "ld_y", "split_y")] + [("ysum_scale", C.c_float)]
+
+
+class Op(C.Structure):
+    """asl_op: one launch as data, for asl_run_ops"""
+    _fields_ = [("kind", C.c_int32), ("stream", C.c_int32), ("params", C.c_void_p), ("ptr", C.c_void_p * 6),
+                ("i", C.c_int32 * 8), ("f", C.c_float * 6)]
+
+
+(OP_CONV2D, OP_STEM_CONV, OP_STEM_POOL, OP_CONV3D, OP_LINEAR, OP_MAXPOOL3D, OP_MAXPOOL, OP_AVGPOOL, OP_PACK_CLIPS,
+ OP_PREPROCESS, OP_MEAN_T, OP_HEAD) = range(1, 13)
 
 
 class AttnParams(C.Structure):
@@ -100,6 +113,7 @@ _PROTOS = {
     "asl_add_rows_f32": ([_P, _I, _I, _P, _I, _P, _P, _I, _P], C.c_int),
     "asl_cast_pad_bf16": ([_P, _I, _I, _P, _I, _P], C.c_int),
     "asl_attention_fwd": ([C.POINTER(AttnParams), _P, _P, _P], C.c_int),
+    "asl_run_ops": ([C.POINTER(Op), _I, C.POINTER(C.c_void_p), _I, C.POINTER(C.c_int)], C.c_int),
 }
 
 EXPORTS = tuple(_PROTOS)
@@ -112,6 +126,28 @@ for _name, (_args, _res) in _PROTOS.items():
 
 def strerror(rc: int) -> str:
     return lib.asl_strerror(rc).decode()
+
+
+def make_op(kind, params=None, ptrs=(), ints=(), floats=(), stream=0) -> Op:
+    o = Op()
+    o.kind, o.stream = kind, stream
+    o.params = C.addressof(params) if params is not None else None
+    for k, p in enumerate(ptrs):
+        o.ptr[k] = p
+    for k, v in enumerate(ints):
+        o.i[k] = v
+    for k, v in enumerate(floats):
+        o.f[k] = v
+    return o
+
+
+def run_ops(ops, count: int, streams, nstreams: int, what: str = "ops") -> None:
+    """ops: ctypes array of Op; streams: ctypes array of c_void_p"""
+    failed = C.c_int(-1)
+    rc = lib.asl_run_ops(ops, count, streams, nstreams, C.byref(failed))
+    if rc != 0:
+        raise RuntimeError(f"{what}: op {failed.value} (kind {ops[failed.value].kind if failed.value >= 0 else '?'}) "
+                           f"failed: rc={rc} ({strerror(rc)})")
 
 
 def check(rc: int, what: str = "") -> None:

@@ -47,7 +47,7 @@ extern "C" int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, c
         g.res.off0 = (p->res_halo * rwp + p->res_halo) * p->res_ctot + p->res_coff;
         g.res_elems = (int64_t)p->n * g.res.sn;
     }
-    g.relu = p->relu; g.out_f32 = 0; g.w_rows = p->w_rows;
+    g.relu = p->relu; g.out_f32 = 0; g.w_rows = p->w_rows; g.variant = p->variant;
     g.x_elems = (int64_t)p->n * g.in.sn;
     return asl_gather_gemm_bf16(&g, x, w, scale, bias, res, y, stream);
 }
@@ -130,4 +130,70 @@ extern "C" int asl_linear_bf16(const asl_linear_params* p, const void* x, const 
     g.y_elems = (int64_t)(p->m - 1) * p->ldy + p->n;
     g.res_elems = (int64_t)(p->m - 1) * p->ldres + p->n;
     return asl_gather_gemm_bf16(&g, x, w, scale, bias, res, y, stream);
+}
+
+extern "C" int asl_run_ops(const asl_op* ops, int count, const asl_stream_t* streams, int nstreams, int* failed) {
+    if (failed) *failed = -1;
+    if (!ops || count < 0 || !streams || nstreams <= 0) return ASL_EINVAL;
+    for (int k = 0; k < count; ++k) {
+        const asl_op& o = ops[k];
+        int rc = ASL_EINVAL;
+        if (o.stream >= 0 && o.stream < nstreams) {
+            asl_stream_t s = streams[o.stream];
+            void* const* p = o.ptr;
+            const int32_t* i = o.i;
+            switch (o.kind) {
+                case ASL_OP_CONV2D:
+                    rc = asl_conv2d_nhwc_bf16((const asl_conv2d_params*)o.params, p[0], p[1], (const float*)p[2],
+                                              (const float*)p[3], p[4], p[5], s);
+                    break;
+                case ASL_OP_STEM_CONV:
+                    rc = asl_stem_conv_bf16((const asl_stem_params*)o.params, p[0], p[1], (const float*)p[2],
+                                            (const float*)p[3], p[4], s);
+                    break;
+                case ASL_OP_STEM_POOL:
+                    rc = asl_stem_pool_bf16((const asl_stem_pool_params*)o.params, p[0], p[1], (const float*)p[2],
+                                            (const float*)p[3], p[4], s);
+                    break;
+                case ASL_OP_CONV3D:
+                    rc = asl_conv3d_ndhwc_bf16((const asl_conv3d_params*)o.params, p[0], p[1], (const float*)p[2],
+                                               (const float*)p[3], p[4], s);
+                    break;
+                case ASL_OP_LINEAR:
+                    rc = asl_linear_bf16((const asl_linear_params*)o.params, p[0], p[1], (const float*)p[2],
+                                         (const float*)p[3], p[4], p[5], s);
+                    break;
+                case ASL_OP_MAXPOOL3D:
+                    rc = asl_maxpool3d_ndhwc((const asl_pool3d_params*)o.params, p[0], p[1], s);
+                    break;
+                case ASL_OP_MAXPOOL:
+                    rc = asl_maxpool3x3s2_nhwc(p[0], i[0], i[1], i[2], i[3], i[4], p[1], i[5], s);
+                    break;
+                case ASL_OP_AVGPOOL:
+                    rc = asl_avgpool_nhwc(p[0], i[0], i[1], i[2], i[3], i[4], (float*)p[1], p[2], i[5], i[6], s);
+                    break;
+                case ASL_OP_PACK_CLIPS:
+                    rc = asl_pack_clips(p[0], i[0], i[1], i[2], i[3], p[1], s);
+                    break;
+                case ASL_OP_PREPROCESS:
+                    rc = asl_preprocess_u8((const uint8_t*)p[0], i[0], i[1], i[2], i[3], i[4], o.f, o.f + 3, p[1],
+                                           (float*)p[2], s);
+                    break;
+                case ASL_OP_MEAN_T:
+                    rc = asl_mean_t_f32((const float*)p[0], i[0], i[1], i[2], (float*)p[1], s);
+                    break;
+                case ASL_OP_HEAD:
+                    rc = asl_head_f32((const float*)p[0], i[0], i[1], (const float*)p[1], (const float*)p[2], i[2],
+                                      (float*)p[3], s);
+                    break;
+                default:
+                    rc = ASL_EINVAL;
+            }
+        }
+        if (rc != ASL_OK) {
+            if (failed) *failed = k;
+            return rc;
+        }
+    }
+    return ASL_OK;
 }

@@ -267,7 +267,8 @@ static int c64_tile(int n, int h, int w, int in_halo) {
 
 // Runs a 64 -> 64 channel request on the persistent kernel; -1 when it does not apply.
 int try_launch_conv3x3_c64(PatchArgs a, int n, hipStream_t stream) {
-    if (a.C != 64 || a.N != 64 || getenv("ASL_NO_C64_CONV")) return -1;
+    if (a.variant != ASL_CONV_AUTO && a.variant != ASL_CONV_C64) return -1;
+    if (a.C != 64 || a.N != 64) return -1;
     if (a.y_bytes <= 0 || a.y_bytes >= 0xffffffffLL || (a.res && (a.res_bytes <= 0 || a.res_bytes >= 0xffffffffLL))) return -1;
     if (a.W <= 0 || a.H <= 0 || (int)a.dOW.d != a.W || (int)a.dOHW.d != a.H * a.W || a.Wp != a.W + 2 * a.in_halo ||
         a.Hp != a.H + 2 * a.in_halo || a.w_bytes < 2LL * 64 * a.wk || a.wk != 9 * 64)
@@ -276,11 +277,10 @@ int try_launch_conv3x3_c64(PatchArgs a, int n, hipStream_t stream) {
     if (!a.bmv) return -1;
     a.tiles_m = (a.M + a.bmv - 1) / a.bmv;
     a.tiles_n = 1;
-    int ncu = device_cus();                            // one persistent workgroup per CU
-    if (const char* e = getenv("ASL_C64_GRID")) ncu = atoi(e) > 0 ? atoi(e) : ncu;
+    const int ncu = device_cus();                      // one persistent workgroup per CU
     const int grid = a.tiles_m < ncu ? a.tiles_m : ncu;
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kC64Lds);
-    if (e != hipSuccess) return (int)e;
+    static unsigned char lds_set[64];
+    if (const int e = ensure_dynamic_lds((const void*)conv3x3_c64_kernel, kC64Lds, lds_set)) return e;
     hipLaunchKernelGGL(conv3x3_c64_kernel, dim3((unsigned)grid), dim3(512), kC64Lds, stream, a);
     return (int)hipGetLastError();
 }

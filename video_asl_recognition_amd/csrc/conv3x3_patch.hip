@@ -256,6 +256,16 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const PatchArgs 
 #endif
 }
 
+int ensure_dynamic_lds(const void* fn, int bytes, unsigned char* done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev >= 0 && __atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0) __atomic_store_n(&done[dev], (unsigned char)1, __ATOMIC_RELEASE);
+    return 0;
+}
+
 int device_cus() {
     static int cached[64] = {0};
     int dev = 0;
@@ -310,21 +320,19 @@ int launch_conv3x3_patch(PatchArgs a, hipStream_t stream) {
     // 128-channel tiles: a third fewer LDS fragment reads per MFMA and half the patch traffic
     // (measured no faster than the 64-channel tile on any ResNet layer: both shapes run ~1.5x the MFMA-bound
     // step time; the wide shape is kept selectable for experiments)
-    const bool wide = a.N > 64 && a.nchunks > 1 && getenv("ASL_PATCH_WIDE");
+    const bool wide = false;   // the 128-channel tile is compiled for experiments only
     a.tiles_n = wide ? (a.N + 127) / 128 : (a.N + 63) / 64;
     // 100 MHz ticks: ~0.2 us per K step is half of a tile's measured duration; only worth it when the
     // grid runs for many rounds of 512 resident workgroups
     a.stagger_ticks = 0;
-    if ((long long)a.tiles_m * a.tiles_n >= 6 * 512 && !getenv("ASL_NO_STAGGER")) a.stagger_ticks = 20 * a.nchunks * 9 + 200;
-    if (const char* e = getenv("ASL_STAGGER_TICKS")) a.stagger_ticks = atoi(e);
-    int lds = kPatchBytes + kStages * 64 * 128;
-    if (const char* e2 = getenv("ASL_PATCH_LDS_PAD")) lds += atoi(e2);
+    if ((long long)a.tiles_m * a.tiles_n >= 6 * 512) a.stagger_ticks = 20 * a.nchunks * 9 + 200;
+    const int lds = kPatchBytes + kStages * 64 * 128;
     // single-chunk layers (C = 64) are prologue/epilogue-bound: 8 waves split that work finer
-    const bool w8 = a.nchunks == 1 && !getenv("ASL_PATCH_4WAVES");
+    const bool w8 = a.nchunks == 1;
+    static unsigned char lds_set[3][64];
     const void* fn = wide ? (const void*)conv3x3_patch_kernel<4, 128>
                           : w8 ? (const void*)conv3x3_patch_kernel<8, 64> : (const void*)conv3x3_patch_kernel<4, 64>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
+    if (const int e = ensure_dynamic_lds(fn, lds, lds_set[wide ? 0 : w8 ? 1 : 2])) return e;
     const dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
     if (wide) hipLaunchKernelGGL((conv3x3_patch_kernel<4, 128>), grid, dim3(256), lds, stream, a);
     else if (w8) hipLaunchKernelGGL((conv3x3_patch_kernel<8, 64>), grid, dim3(512), lds, stream, a);

@@ -356,8 +356,8 @@ static int pp_launch(PatchArgs a, hipStream_t stream) {
     using S = PpShape<FM_>;
     a.tiles_m = (a.M + a.bmv - 1) / a.bmv;
     a.tiles_n = (a.N + S::TN - 1) / S::TN;
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_pp_kernel<FM_>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS);
-    if (e != hipSuccess) return (int)e;
+    static unsigned char lds_set[64];
+    if (const int e = ensure_dynamic_lds((const void*)conv3x3_pp_kernel<FM_>, S::LDS, lds_set)) return e;
     hipLaunchKernelGGL((conv3x3_pp_kernel<FM_>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), S::LDS, stream, a);
     return (int)hipGetLastError();
 }
@@ -365,17 +365,20 @@ static int pp_launch(PatchArgs a, hipStream_t stream) {
 // Runs the request on the large-tile kernel when it fits: C a multiple of 32 and at least 128, N a multiple
 // of 128.  Returns -1 when it does not apply (the caller falls back).
 int try_launch_conv3x3_pp(PatchArgs a, int n, hipStream_t stream) {
-    if (a.C % 32 || a.C < 128 || a.N % 128 || getenv("ASL_NO_PP_CONV")) return -1;
+    if (a.variant != ASL_CONV_AUTO && a.variant != ASL_CONV_PP && a.variant != ASL_CONV_PP_BIG) return -1;
+    if (a.C % 32 || a.C < 128 || a.N % 128) return -1;
     if (a.y_bytes <= 0 || a.y_bytes >= 0xffffffffLL || (a.res && (a.res_bytes <= 0 || a.res_bytes >= 0xffffffffLL))) return -1;
     if (a.W <= 0 || a.H <= 0 || (int)a.dOW.d != a.W || (int)a.dOHW.d != a.H * a.W || a.Wp != a.W + 2 * a.in_halo ||
         a.Hp != a.H + 2 * a.in_halo)
         return -1;
-    if (!getenv("ASL_PP_BIG")) {
+    if (a.variant != ASL_CONV_PP_BIG) {
         a.bmv = pp_tile<4>(n, a.H, a.W, a.in_halo);
         if (a.bmv) return pp_launch<4>(a, stream);
     }
-    a.bmv = pp_tile<8>(n, a.H, a.W, a.in_halo);
-    if (a.bmv) return pp_launch<8>(a, stream);
+    if (a.variant != ASL_CONV_PP) {
+        a.bmv = pp_tile<8>(n, a.H, a.W, a.in_halo);
+        if (a.bmv) return pp_launch<8>(a, stream);
+    }
     return -1;
 }
 

@@ -321,11 +321,9 @@ __global__ __launch_bounds__(1024) void conv3x3_wide_kernel(const PatchArgs a) {
 // 128, a 512-pixel (or whole-image) tile whose patch fits.  Returns -1 when it does not apply.
 int try_launch_conv3x3_wide(PatchArgs a, int n, hipStream_t stream) {
     using S = WideShape;
-    if (a.C % 64 || a.C < 128 || a.N % 128 || getenv("ASL_NO_WIDE_CONV")) return -1;
-    {
-        const char* e = getenv("ASL_WIDE_MIN_C");
-        if (a.C < (e ? atoi(e) : 512)) return -1;      // measured: ahead of the 8-wave kernel from 512 channels up
-    }
+    if (a.variant != ASL_CONV_AUTO && a.variant != ASL_CONV_WIDE) return -1;
+    if (a.C % 64 || a.C < 128 || a.N % 128) return -1;
+    if (a.variant == ASL_CONV_AUTO && a.C < 512) return -1;   // measured: ahead of the 8-wave kernel from 512 channels up
     if (a.y_bytes <= 0 || a.y_bytes >= 0xffffffffLL || (a.res && (a.res_bytes <= 0 || a.res_bytes >= 0xffffffffLL))) return -1;
     if (a.W <= 0 || a.H <= 0 || (int)a.dOW.d != a.W || (int)a.dOHW.d != a.H * a.W || a.Wp != a.W + 2 * a.in_halo ||
         a.Hp != a.H + 2 * a.in_halo)
@@ -343,9 +341,9 @@ int try_launch_conv3x3_wide(PatchArgs a, int n, hipStream_t stream) {
     a.tiles_n = (a.N + S::TN - 1) / S::TN;
     // one workgroup per CU: a grid that leaves a quarter of the CUs idle is better served by the 256-pixel
     // workgroups of the 8-wave kernel (layer 4, 256 frames: 104 tiles, 0.090 ms here against 0.065 there)
-    if ((long long)a.tiles_m * a.tiles_n * 4 < 3LL * device_cus() && !getenv("ASL_WIDE_ANY_GRID")) return -1;
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS);
-    if (e != hipSuccess) return (int)e;
+    if (a.variant == ASL_CONV_AUTO && (long long)a.tiles_m * a.tiles_n * 4 < 3LL * device_cus()) return -1;
+    static unsigned char lds_set[64];
+    if (const int e = ensure_dynamic_lds((const void*)conv3x3_wide_kernel, S::LDS, lds_set)) return e;
     hipLaunchKernelGGL(conv3x3_wide_kernel, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(1024), S::LDS, stream, a);
     return (int)hipGetLastError();
 }

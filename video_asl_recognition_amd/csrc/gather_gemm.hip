@@ -246,6 +246,7 @@ using namespace asl_detail;
 extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, const void* w, const float* scale,
                                     const float* bias, const void* res, void* y, asl_stream_t stream) {
     if (!p || !x || !w || !y) return ASL_EINVAL;
+    if (p->variant < ASL_CONV_AUTO || p->variant > ASL_CONV_C64 || p->reserved != 0) return ASL_EINVAL;
     if (p->nb <= 0 || p->od <= 0 || p->oh <= 0 || p->ow <= 0 || p->cout <= 0) return ASL_EINVAL;
     if (p->kd <= 0 || p->kh <= 0 || p->kw <= 0 || p->ck <= 0 || (p->ck & 31)) return ASL_EINVAL;
     if (p->tap_sd < 0 || p->tap_sh < 0 || p->tap_sw < 0) return ASL_EINVAL;
@@ -299,7 +300,7 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
     // 3x3 / stride 1 / pad 1 on a halo'd NHWC tensor with C % 64 == 0: the LDS-resident-patch kernel
     if (p->kd == 1 && p->kh == 3 && p->kw == 3 && p->od == 1 && (p->ck & 63) == 0 && !p->out_f32 && !p->res_f32 &&
         p->tap_sw == p->ck && p->in.sw == p->ck && p->in.sh == p->tap_sh && p->tap_sh % p->ck == 0 &&
-        p->in.sn % p->tap_sh == 0 && !getenv("ASL_NO_PATCH_CONV")) {
+        p->in.sn % p->tap_sh == 0 && p->variant != ASL_CONV_GATHER) {
         const int C = p->ck, Wp = p->tap_sh / C, Hp = (int)(p->in.sn / p->tap_sh);
         const int halo = (Wp - p->ow) / 2;
         if (halo >= 1 && Wp == p->ow + 2 * halo && Hp == p->oh + 2 * halo &&
@@ -311,7 +312,7 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
             b.y_bytes = 2 * p->y_elems; b.res_bytes = res ? 2 * p->res_elems : 0;
             b.out_sn = a.out_sn; b.out_sh = a.out_sh; b.out_sw = a.out_sw; b.out_off0 = a.out_off0;
             b.res_sn = a.res_sn; b.res_sh = a.res_sh; b.res_sw = a.res_sw; b.res_off0 = a.res_off0;
-            b.relu = a.relu; b.tiles_m = b.tiles_n = 0; b.stamps = nullptr;
+            b.relu = a.relu; b.tiles_m = b.tiles_n = 0; b.stamps = nullptr; b.variant = p->variant;
 #if defined(ASL_STAMPS)
             if (const char* e = getenv("ASL_STAMP_PTR")) b.stamps = (unsigned long long*)strtoull(e, nullptr, 16);
 #endif
@@ -322,9 +323,12 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
             if (r >= 0) return r;
             r = try_launch_conv3x3_pp(b, p->nb, s);                // C >= 128: 8-wave ping-pong workgroups
             if (r >= 0) return r;
-            if ((b.bmv = patch_conv_tile(p->nb, p->oh, p->ow, halo)) > 0) return launch_conv3x3_patch(b, s);
+            if ((p->variant == ASL_CONV_AUTO || p->variant == ASL_CONV_PATCH) &&
+                (b.bmv = patch_conv_tile(p->nb, p->oh, p->ow, halo)) > 0)
+                return launch_conv3x3_patch(b, s);
         }
     }
+    if (p->variant > ASL_CONV_GATHER) return ASL_ENOTSUP;       // the forced kernel does not take this request
     if (p->ck % 64 == 0) {
         a.ksteps_per_tap = p->ck / 64;
         if (p->cout <= 64) return launch<128, 64, 64, 2, 2>(a, s);

@@ -30,10 +30,14 @@ struct PatchArgs {
     int tiles_m, tiles_n;
     unsigned long long* stamps;   // diagnostic builds only (ASL_STAMPS): 5 s_memtime stamps per workgroup
     int stagger_ticks;     // one-time start delay (100 MHz ticks) of the second resident workgroup set
+    int variant;           // ASL_CONV_* requested by the caller (0: the library chooses)
 };
 
 // compute units of the current device (cached per device; 256 when the query fails)
 int device_cus();
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per launch:
+// `done` is the kernel's own table of per-device flags
+int ensure_dynamic_lds(const void* fn, int bytes, unsigned char* done);
 long long max_patch_pixels(int n, int h, int w, int in_halo, int bmv);
 int patch_conv_tile(int n, int h, int w, int in_halo);
 // large-tile kernel (conv3x3_pp.hip): returns -1 when the request does not fit it

@@ -80,6 +80,10 @@ class AslClipModel:
         self.streams = int(streams)
         self._streams: List[torch.cuda.Stream] = []
         self._plan = None
+        self._groups: Dict[int, tuple] = {}
+        # diagnostics / A-B runs: force one conv kernel variant (L.CONV_*), run stem and max-pool unfused
+        self.conv_variant = int(os.environ.get("ASL_CONV_VARIANT", "0"))
+        self.fused_stem = not os.environ.get("ASL_NO_FUSED_STEM")
         self._w: Dict[str, PackedConv] = {}
         self._fc_w = self._fc_b = None
         self._temporal = None
@@ -132,39 +136,35 @@ class AslClipModel:
             from .temporal import build_temporal
             self._temporal = build_temporal(spec, sd, dev)
         self._plan = None
+        self._groups = {}
         return self
 
     # ------------------------------------------------------------------ plan
     def _build_plan(self, nmax: int):
+        """The backbone of one chunk of up to `nmax` frames as data: a list of asl_op records (L.Op) over
+        buffers allocated here, issued by one asl_run_ops call per group of chunks."""
         spec, dev = self.spec, self.device
         pool = _BufPool(nmax, dev)
-        ops = []            # callables (n, stream)
-        S = spec.size
+        ops = []            # dicts: op (L.Op template), params (struct with a field n, or None), n_slot (index of n
+        S = spec.size       # in op.i, or None), conv (priced by the roofline), keep (tensors the pointers refer to)
+
+        def add(kind, params, ptrs, ints=(), n_slot=None, conv=False, keep=()):
+            ops.append(dict(op=L.make_op(kind, params, [t.data_ptr() if t is not None else None for t in ptrs], ints),
+                            params=params, n_slot=n_slot, conv=conv, keep=(params, ptrs, keep)))
 
         def conv_op(pc: PackedConv, x: Act, y: Act, stride, pad, relu, res: Optional[Act] = None):
             kd, kh, kw = pc.k
             p = L.Conv2dParams(n=0, h=x.h, w=x.w, cin=x.c, in_halo=x.halo, cout=pc.cout, kh=kh, kw=kw,
                                stride=stride, pad=pad, out_halo=y.halo, out_ctot=y.c, out_coff=0,
                                res_halo=res.halo if res else 0, res_ctot=res.c if res else 0, res_coff=0,
-                               relu=int(relu), w_rows=pc.w_rows)
-            args = (_ptr(x.t), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(res.t if res else None), _ptr(y.t))
-            keep = (x, y, res, pc)
-
-            def run(n, stream, p=p, args=args, keep=keep):
-                p.n = n
-                L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(p), *args, stream), "conv2d")
-            ops.append(run)
+                               relu=int(relu), w_rows=pc.w_rows, variant=self.conv_variant)
+            add(L.OP_CONV2D, p, (x.t, pc.w, pc.scale, pc.bias, res.t if res else None, y.t), conv=True, keep=(x, y, res, pc))
 
         def stem_op(pc: PackedConv, x0: torch.Tensor, in_halo, y: Act, stride, pad, relu):
             kd, kh, kw = pc.k
             p = L.StemParams(n=0, h=S, w=S, in_halo=in_halo, cout=pc.cout, kh=kh, kw=kw, stride=stride, pad=pad,
                              out_halo=y.halo, relu=int(relu), w_rows=pc.w_rows)
-            args = (_ptr(x0), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(y.t))
-
-            def run(n, stream, p=p, args=args, keep=(x0, y, pc)):
-                p.n = n
-                L.check(L.lib.asl_stem_conv_bf16(C.byref(p), *args, stream), "stem")
-            ops.append(run)
+            add(L.OP_STEM_CONV, p, (x0, pc.w, pc.scale, pc.bias, y.t), conv=True, keep=(y, pc))
 
         if spec.backbone == "tiny":
             in_halo = 5         # (ow-1)*2 - 1 + 8 - S for the 3x3/2/1 first layer
@@ -177,24 +177,15 @@ class AslClipModel:
             in_halo = 3
             x0 = torch.zeros(nmax, S + 6, S + 6, 4, dtype=torch.bfloat16, device=dev)
             x = pool.get(S // 4, S // 4, 64)
-            if os.environ.get("ASL_NO_FUSED_STEM"):
+            if not self.fused_stem:
                 a = pool.get(S // 2, S // 2, 64)
                 stem_op(self._w["stem"], x0, in_halo, a, 2, 3, True)
-
-                def maxpool(n, stream, a=a, x=x):
-                    L.check(L.lib.asl_maxpool3x3s2_nhwc(_ptr(a.t), n, a.h, a.w, a.c, a.halo, _ptr(x.t), x.halo, stream),
-                            "maxpool")
-                ops.append(maxpool)
+                add(L.OP_MAXPOOL, None, (a.t, x.t), (0, a.h, a.w, a.c, a.halo, x.halo), n_slot=0, keep=(a, x))
                 pool.put(a)
             else:
                 pc = self._w["stem"]
                 sp = L.StemPoolParams(n=0, h=S, w=S, cout=pc.cout, out_halo=x.halo, w_rows=pc.w_rows)
-                sargs = (_ptr(x0), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(x.t))
-
-                def run(n, stream, sp=sp, sargs=sargs, keep=(x0, x, pc)):
-                    sp.n = n
-                    L.check(L.lib.asl_stem_pool_bf16(C.byref(sp), *sargs, stream), "stem+pool")
-                ops.append(run)
+                add(L.OP_STEM_POOL, sp, (x0, pc.w, pc.scale, pc.bias, x.t), conv=True, keep=(x, pc))
             basic = RESNET_LAYERS[spec.backbone][0] == "basic"
             for prefix, cin, planes, stride, ds in resnet_blocks(spec.backbone):
                 oh, ow = x.h // stride, x.w // stride
@@ -229,13 +220,43 @@ class AslClipModel:
         plan = {"x0": x0, "in_halo": in_halo, "ops": ops, "last": x, "pool": pool, "nmax": nmax}
         return plan
 
+    def _group_array(self, plans, g: int):
+        """asl_op array for a group of g chunks (chunk j on plan j and stream j): g fill ops, then the plans'
+        ops interleaved op by op across the group (so every stream gets work early), then g avg-pools.  Built
+        once per group size; per call only n, the fill source and the pool destinations change."""
+        cache = self._groups
+        if g not in cache:
+            nops = len(plans[0]["ops"])
+            arr = (L.Op * (g + nops * g + g))()
+            n_slots = [[] for _ in range(g)]           # (array index, slot in i[]) that take this chunk's n
+            for j in range(g):
+                arr[j].stream = j
+                for i, rec in enumerate(plans[j]["ops"]):
+                    k = g + i * g + j
+                    C.memmove(C.addressof(arr[k]), C.addressof(rec["op"]), C.sizeof(L.Op))
+                    arr[k].stream = j
+                    if rec["n_slot"] is not None:
+                        n_slots[j].append((k, rec["n_slot"]))
+                last: Act = plans[j]["last"]
+                k = g + nops * g + j
+                arr[k].kind, arr[k].stream = L.OP_AVGPOOL, j
+                arr[k].ptr[0] = last.t.data_ptr()
+                for q, v in enumerate((0, last.h, last.w, last.c, last.halo)):
+                    arr[k].i[q] = v
+                n_slots[j].append((k, 0))
+            cache[g] = (arr, n_slots, nops)
+        return cache[g]
+
     # ------------------------------------------------------------------ backbone
     def _run_backbone(self, n_total: int, fill_x0, want_bf16: bool):
-        """fill_x0(c0, n, x0, in_halo, stream) writes frames [c0, c0+n) into the packed stem input.
+        """fill_x0(op, c0, n, x0_ptr, in_halo) turns `op` (an L.Op) into the launch that writes frames
+        [c0, c0+n) into the packed stem input at x0_ptr.
 
         Chunks alternate between `self.streams` HIP streams (each with its own workspace), so one
         chunk's kernels fill the CUs another chunk's kernel leaves idle in its last, partial round of
-        workgroups and during its per-tile load/store phases."""
+        workgroups and during its per-tile load/store phases.  Each group of chunks is issued by ONE
+        asl_run_ops call, op by op across the group, so the host pays one foreign call per group and the
+        second stream starts a launch after the first."""
         F = self.spec.feat_dim
         feats = torch.empty(n_total, F, dtype=torch.float32, device=self.device)
         # bf16 copy of the features = GEMM operand of the temporal encoder; the two-stream model appends
@@ -251,28 +272,32 @@ class AslClipModel:
         plans = self._get_plans(step, nstreams)
         main = torch.cuda.current_stream()
         side = self._side_streams(nstreams)
-        for s_ in side:
-            s_.wait_stream(main)
-        # Chunks are issued in groups of `nstreams`, op by op across the group: the host needs ~15 us per
-        # launch, so issuing one chunk's ~23 launches before the next chunk's first would start the second
-        # stream more than 0.3 ms late and leave it running alone at the end.
+        if nstreams > 1:
+            for s_ in side:
+                s_.wait_stream(main)
+            sarr = (C.c_void_p * nstreams)(*[s_.cuda_stream for s_ in side])
+        else:
+            sarr = (C.c_void_p * 1)(main.cuda_stream)
         starts = list(range(0, n_total, step))
+        fbase, bbase = feats.data_ptr(), (feats_b.data_ptr() if feats_b is not None else 0)
         for g0 in range(0, len(starts), nstreams):
-            group = []
-            for k in range(g0, min(g0 + nstreams, len(starts))):
-                plan = plans[k % nstreams]
-                st = main if nstreams == 1 else side[k % nstreams]
-                group.append((plan, C.c_void_p(st.cuda_stream), starts[k], min(step, n_total - starts[k])))
-            for plan, stream, c0, n in group:
-                fill_x0(c0, n, plan["x0"], plan["in_halo"], stream)
-            for i in range(len(group[0][0]["ops"])):
-                for plan, stream, c0, n in group:
-                    plan["ops"][i](n, stream)
-            for plan, stream, c0, n in group:
-                last: Act = plan["last"]
-                fb = None if feats_b is None else C.c_void_p(feats_b.data_ptr() + c0 * ld_b * 2)
-                L.check(L.lib.asl_avgpool_nhwc(_ptr(last.t), n, last.h, last.w, last.c, last.halo,
-                                               C.c_void_p(feats.data_ptr() + c0 * F * 4), fb, ld_b, lo_off, stream), "avgpool")
+            g = min(nstreams, len(starts) - g0)
+            arr, n_slots, nops = self._group_array(plans, g)
+            for j in range(g):
+                c0 = starts[g0 + j]
+                n = min(step, n_total - c0)
+                plan = plans[j]
+                fill_x0(arr[j], c0, n, plan["x0"].data_ptr(), plan["in_halo"])
+                for rec in plan["ops"]:
+                    if rec["params"] is not None:
+                        rec["params"].n = n
+                for k, slot in n_slots[j]:
+                    arr[k].i[slot] = n
+                avg = arr[g + nops * g + j]
+                avg.ptr[1] = fbase + c0 * F * 4
+                avg.ptr[2] = (bbase + c0 * ld_b * 2) if feats_b is not None else None
+                avg.i[5], avg.i[6] = ld_b, lo_off
+            L.run_ops(arr, len(arr), sarr, nstreams, "backbone")
         if nstreams > 1:
             for s_ in side:
                 main.wait_stream(s_)
@@ -286,6 +311,7 @@ class AslClipModel:
     def _get_plans(self, nmax: int, count: int):
         if self._plan is None or self._plan[0]["nmax"] < nmax or len(self._plan) < count:
             self._plan = [self._build_plan(nmax) for _ in range(count)]
+            self._groups = {}
         return self._plan
 
     def frame_features(self, clips: torch.Tensor, want_bf16: bool = False):
@@ -296,9 +322,10 @@ class AslClipModel:
         in_f32 = int(clips.dtype == torch.float32)
         base = clips.data_ptr()
 
-        def fill(c0, n, x0, in_halo, stream):
-            L.check(L.lib.asl_pack_clips(C.c_void_p(base + c0 * 3 * S * S * esz), in_f32, n, S, in_halo,
-                                         _ptr(x0), stream), "pack_clips")
+        def fill(op, c0, n, x0_ptr, in_halo):
+            op.kind = L.OP_PACK_CLIPS
+            op.ptr[0], op.ptr[1] = base + c0 * 3 * S * S * esz, x0_ptr
+            op.i[0], op.i[1], op.i[2], op.i[3] = in_f32, n, S, in_halo
         return self._run_backbone(B * T, fill, want_bf16)
 
     def _check_clips(self, clips):
@@ -395,9 +422,12 @@ class AslClipModel:
         std = (C.c_float * 3)(*IMAGENET_STD)
         base = frames.data_ptr()
 
-        def fill(c0, n, x0, in_halo, stream):
-            L.check(L.lib.asl_preprocess_u8(C.c_void_p(base + c0 * H0 * W0 * 3), n, H0, W0, S, in_halo, mean, std,
-                                            _ptr(x0), None, stream), "preprocess")
+        def fill(op, c0, n, x0_ptr, in_halo):
+            op.kind = L.OP_PREPROCESS
+            op.ptr[0], op.ptr[1], op.ptr[2] = base + c0 * H0 * W0 * 3, x0_ptr, None
+            op.i[0], op.i[1], op.i[2], op.i[3], op.i[4] = n, H0, W0, S, in_halo
+            for q in range(3):
+                op.f[q], op.f[3 + q] = IMAGENET_MEAN[q], IMAGENET_STD[q]
         if self.spec.backbone == "i3d":
             def fill3(f0, n, dst, stream):
                 L.check(L.lib.asl_preprocess_u8(C.c_void_p(base + f0 * H0 * W0 * 3), n, H0, W0, S, 3, mean, std, dst,
