@@ -295,15 +295,23 @@ def bf16_round_(t):
 
 
 @torch.no_grad()
-def init_params(model, seed):
-    """Seeded init with non-trivial BN statistics; every float ends up bf16-representable."""
+def init_params(model, seed, recipe="conditioned"):
+    """Seeded init with non-trivial BN statistics; every float ends up bf16-representable.
+
+    recipe "conditioned" (the gate of the parity tests): as described in the comments below.
+    recipe "plain": every BatchNorm gamma ~ U(0.5, 1.5) and fan-out He init for every conv, 3-D included --
+    the first recipe this build specified; a random-init deep trunk grows by ~sqrt(2) per residual block under
+    it, which is what the conditioned recipe removes.  Kept so that the path's error under it can be reported."""
+    if recipe not in ("conditioned", "plain"):
+        raise ValueError(recipe)
     g = torch.Generator().manual_seed(seed)
     for m in model.modules():
         if isinstance(m, (nn.Conv2d, nn.Conv3d)):
             # He-normal: fan_out for the ResNets (torchvision's choice); fan_in for the Inception-style 3-D
             # net, whose 1x1x1 bottlenecks change the channel count by up to 12x per layer -- fan_out there
             # multiplies the forward variance by cin/cout each time (random-init logits of std ~1e3)
-            fan = m.weight[0].numel() if isinstance(m, nn.Conv3d) else m.weight.shape[0] * m.weight[0, 0].numel()
+            fan_in = isinstance(m, nn.Conv3d) and recipe == "conditioned"
+            fan = m.weight[0].numel() if fan_in else m.weight.shape[0] * m.weight[0, 0].numel()
             m.weight.normal_(0.0, math.sqrt(2.0 / fan), generator=g)
             if m.bias is not None:
                 m.bias.normal_(0.0, 0.1, generator=g)
@@ -318,6 +326,8 @@ def init_params(model, seed):
     # ten-fold; a trained network (and torchvision's zero_init_residual) keeps the trunk O(1), and so
     # does this.
     for m in model.modules():
+        if recipe != "conditioned":
+            break
         if isinstance(m, BasicBlock):
             m.bn2.weight.uniform_(0.2, 0.6, generator=g)
         elif isinstance(m, Bottleneck):
@@ -349,11 +359,11 @@ def init_params(model, seed):
     return model
 
 
-def build(name, num_classes=None, seed=0):
+def build(name, num_classes=None, seed=0, recipe="conditioned"):
     spec = SPECS[name]
     torch.backends.mha.set_fastpath_enabled(False)
     m = ClipModel(name, num_classes or spec.num_classes)
-    init_params(m, seed)
+    init_params(m, seed, recipe)
     return m.eval()
 
 

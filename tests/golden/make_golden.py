@@ -39,8 +39,18 @@ def classify_case(name, B, T, S, H0, W0, seed, topk=5):
     print(name, "classify", idx[0].tolist())
 
 
+def full_length_cases():
+    """the configurations' own sequence lengths (minutes of CPU time): `python make_golden.py full`"""
+    forward_case("resnet50_bilstm", 1, 64, 224, 0, heavy=1)
+    forward_case("twostream_transformer", 1, 128, 224, 0, heavy=1)
+    forward_case("i3d", 2, 64, 224, 0, heavy=1)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["full"]:
+        full_length_cases()
+        sys.exit(0)
     forward_case("tiny", 2, 8, 112, 0)
     classify_case("tiny", 2, 8, 112, 60, 80, 0)
     forward_case("resnet18_mean", 2, 8, 224, 0)

@@ -161,6 +161,41 @@ def test_resnet50_bilstm_matches_oracle(gpu):
     assert torch.equal(y.argmax(1), ref.argmax(1))
 
 
+def test_resnet50_bilstm_full_length_matches_golden(gpu):
+    """the configuration's own sequence length: 64 frames through ResNet-50 and the 2 x 64-step recurrence"""
+    om, m = _model("resnet50_bilstm", frames_per_chunk=64)
+    g = np.load(os.path.join(GOLDEN, "resnet50_bilstm_fwd_b1t64s224.npz"))
+    clips = O.make_clips(1, 64, 224, 0)
+    y = m(clips.cuda()).cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert rel_l2(y, ref) <= REL_TOL, rel_l2(y, ref)
+    assert torch.equal(y.argmax(1), ref.argmax(1))
+
+
+def test_twostream_transformer_full_length_matches_golden(gpu):
+    """128 tokens (the attention kernel's limit), 2000 classes"""
+    om, m = _model("twostream_transformer", frames_per_chunk=128)
+    g = np.load(os.path.join(GOLDEN, "twostream_transformer_fwd_b1t128s224.npz"))
+    clips, kp = O.make_clips(1, 128, 224, 0), O.make_keypoints(1, 128, 0)
+    y = m(clips.cuda(), kp.cuda()).cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert y.shape == (1, 2000)
+    assert rel_l2(y, ref) <= REL_TOL, rel_l2(y, ref)
+    assert torch.equal(y.argmax(1), ref.argmax(1))
+
+
+def test_i3d_two_clips_full_length_matches_golden(gpu):
+    """two 64-frame clips: the clip axis of the 3-D backbone (separate zero-padded depth ranges per clip)"""
+    om, m = _model("i3d", frames_per_chunk=128)
+    g = np.load(os.path.join(GOLDEN, "i3d_fwd_b2t64s224.npz"))
+    clips = O.make_clips(2, 64, 224, 0)
+    y = m(clips.cuda()).cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert y.shape == (2, 100)
+    assert rel_l2(y, ref) <= REL_TOL, rel_l2(y, ref)
+    assert torch.equal(y.argmax(1), ref.argmax(1))
+
+
 def test_twostream_transformer_matches_oracle(gpu):
     om, m = _model("twostream_transformer", frames_per_chunk=32)
     g = np.load(os.path.join(GOLDEN, "twostream_transformer_fwd_b2t16s224.npz"))

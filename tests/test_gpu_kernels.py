@@ -90,6 +90,27 @@ def test_large_tile_conv_variants(gpu, variant, n, h, w, cin, cout, k, stride, p
     _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu, variant=getattr(L, variant))
 
 
+# the generic gather-GEMM on the shapes only it takes: one tap and many, strided, short and ragged tiles,
+# channel counts below and between its 128-wide tiles
+GATHER_CASES = [
+    (3, 28, 28, 64, 128, 1, 2, 0, False, False),     # 1x1 stride 2 (ResNet downsample)
+    (2, 14, 14, 256, 1024, 1, 1, 0, True, True),     # bottleneck expansion with residual
+    (5, 56, 56, 64, 256, 1, 1, 0, True, True),       # K = 64: two steps, a single K step
+    (4, 28, 28, 512, 128, 1, 1, 0, False, True),     # bottleneck reduction, 16 steps
+    (1, 1, 1, 64, 64, 1, 1, 0, False, False),        # one row
+    (7, 9, 13, 32, 64, 3, 2, 1, False, True),        # 3x3 stride 2, K chunks of 32, 64 of 128 tile channels
+    (3, 28, 28, 64, 128, 3, 2, 1, False, True),
+    (6, 20, 20, 192, 200, 3, 1, 1, True, True),      # channel count between tiles (200 = 128 + 72)
+    (9, 7, 7, 96, 40, 1, 1, 0, True, False),         # 40 output channels
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,res,relu", GATHER_CASES)
+def test_gather_gemm_conv_shapes(gpu, n, h, w, cin, cout, k, stride, pad, res, relu):
+    from video_asl_recognition_amd import _lib as L
+    _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu, variant=L.CONV_GATHER)
+
+
 def test_forced_variant_that_does_not_fit_is_refused(gpu):
     from video_asl_recognition_amd import _lib as L
     for variant in (L.CONV_C64, L.CONV_PP, L.CONV_WIDE):      # a 1x1 conv fits none of the 3x3 kernels
@@ -212,7 +233,8 @@ def test_avgpool_mean_head(gpu, c):
     torch.testing.assert_close(logits.cpu(), ref_pooled @ w.T + b, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("m,n,k", [(5, 100, 512), (256, 2048, 2048), (130, 384, 96), (64, 4096, 1024)])
+@pytest.mark.parametrize("m,n,k", [(5, 100, 512), (256, 2048, 2048), (130, 384, 96), (64, 4096, 1024),
+                                   (1000, 200, 64), (300, 100, 96), (1024, 4096, 2048)])
 def test_linear(gpu, m, n, k):
     from video_asl_recognition_amd import _lib as L
     from video_asl_recognition_amd.packing import pack_linear

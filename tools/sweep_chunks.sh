@@ -1,7 +1,9 @@
-#!/bin/bash
-# Times bench.py over (frames per chunk, streams); prints clips/s per configuration.
-for cfg in "256 2" "128 2" "128 4" "192 3" "64 4" "64 8" "128 3" "256 3" "512 1"; do
+# frames per chunk x streams x clips per step: one bench line each (clips/s, ms per step)
+set -e
+O=gpurun_out/sweep
+mkdir -p $O
+for cfg in "8 256 2" "10 640 1" "20 640 2" "10 320 2" "20 320 2" "5 320 1" "16 512 2" "15 320 3" "10 334 2" "21 668 2"; do
   set -- $cfg
-  out=$(timeout -k 10 200 python bench.py --no-cpu-baseline --steps 30 --warmup 5 --chunk $1 --streams $2 2>/dev/null | tail -1) || exit 1
-  echo "chunk $1 streams $2: $(echo "$out" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"
+  out=$(timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 --warmup 3 --clips $1 --chunk $2 --streams $3 2>/dev/null | tail -1) || exit 1
+  echo "clips=$1 chunk=$2 streams=$3 $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["serial_frac"])')" | tee -a $O/sweep.log
 done

@@ -16,30 +16,11 @@
 #include "common.h"
 #include "epilogue.h"
 #include "patch_args.h"
+#include "gemm_args.h"
 #include <stdlib.h>
 
 namespace asl_detail {
 
-struct GemmArgs {
-    const char* x;
-    const char* w;
-    const float* scale;
-    const float* bias;
-    const char* res;
-    char* y;
-    int M, N;
-    FastDiv dOW, dOHW, dODHW;
-    long long in_sn, out_sn, res_sn;
-    int in_sd, in_sh, in_sw, in_off0;
-    int out_sd, out_sh, out_sw, out_off0;
-    int res_sd, res_sh, res_sw, res_off0;
-    int KH, KW, ksteps_per_tap, ntaps;
-    int tap_sd, tap_sh, tap_sw;
-    int wk;                      // packed K (elements per weight row)
-    long long x_bytes, w_bytes;
-    int relu, out_f32, res_f32;
-    int tiles_m, tiles_n;
-};
 
 // LDS chunk swizzle: slot (row, c') of a staged tile holds 16-byte chunk c' ^ swz(row) of that
 // row.  Chosen so that a 16-row x 16-byte fragment read (ds_read_b128) is bank-conflict
