@@ -18,86 +18,83 @@ __device__ __forceinline__ float tanhf_(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// One time step of one bidirectional LSTM layer, both directions.  Wave = (direction, hidden unit j):
-// its 64 lanes split the K axis of the four gate rows W_hh[gate*H + j] (bf16, 16 bytes per lane, read
-// once) against h_prev of up to four batch rows at a time (fp32), the partial sums are reduced across
-// the wave, and lanes 0..3 finish one batch row each: fused gate math and state update.  A step is a
-// single round of coalesced loads instead of a 64-deep dependent chain per thread.  h is kept in fp32
-// for the recurrence; the bf16 copy written to y feeds the next layer's input GEMM.
+// One time step of one bidirectional LSTM layer, both directions, on the matrix cores (hidden % 32 == 0):
+// wave = (direction, four consecutive hidden units).
+// The A operand is the 16 x K slab of W_hh holding the four gates of those units, rows permuted so that MFMA
+// row 4u + g is gate g of unit u; the B operand is h_prev of 16 batch rows, kept as a bf16 pair hi + lo
+// (h to ~16 mantissa bits), so every product is exact and the sums are fp32.  The accumulator layout then puts
+// all four gate pre-activations of (unit fq, batch row fr) in ONE lane: gate math and state update need no
+// cross-lane traffic at all, and a step is one round of 16-byte loads, 2 * K/32 MFMAs and a few stores.
 // ---------------------------------------------------------------------------------------------
-struct LstmArgs {
-    const float* gx;       // [B*T][ld_gx] fp32: x W_ih^T + b_ih + b_hh, forward gates then reverse gates
+struct LstmMfmaArgs {
+    const float* gx;       // [B*T][ld_gx]
     const short* whh;      // [2][4H][H] bf16
-    const float* h_prev;   // [2][B][H]
-    float* h_next;         // [2][B][H]
+    const short* h_prev;   // [2 (hi, lo)][2 (direction)][B][H] bf16
+    short* h_next;         // same layout
     float* c;              // [2][B][H]
-    short* y;              // [B*T][ld_y] bf16: forward h at column 0, reverse h at column H
-    float* ysum;           // [B][2H] fp32 running sum over t (mean-pool numerator), or null
+    short* y;
+    float* ysum;
     int B, T, H, ld_gx, ld_y, step, split_y;
     float ysum_scale;
 };
 
-__global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);          // (direction, unit)
-    const int H = a.H;
-    if (wid >= 2 * H) return;
-    const int d = wid / H, j = wid - d * H;
+__global__ __launch_bounds__(64) void lstm_step_mfma_kernel(const LstmMfmaArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x, fr = lane & 15, fq = lane >> 4;
+    const int H = a.H, groups = H >> 2;
+    const int d = blockIdx.x / groups, j0 = (blockIdx.x - d * groups) * 4;
     const int t = d == 0 ? a.step : a.T - 1 - a.step;
-    const short* w = a.whh + (long long)d * 4 * H * H + (long long)j * H;
-    for (int b0 = 0; b0 < a.B; b0 += 4) {
-        const int nb = a.B - b0 < 4 ? a.B - b0 : 4;
-        float acc[4][4];
+    // A fragment of k-step ks: row fr = (unit fr >> 2, gate fr & 3), elements ks*32 + fq*8 .. +7
+    const short* wrow = a.whh + ((long long)d * 4 * H + (long long)(fr & 3) * H + j0 + (fr >> 2)) * H + fq * 8;
+    const long long lo_off = 2LL * a.B * H;                     // hi plane -> lo plane
+    const int ksteps = H >> 5;
+    for (int b0 = 0; b0 < a.B; b0 += 16) {
+        const int bcol = b0 + fr;                               // this lane's batch row as B-operand column
+        const bool colok = bcol < a.B;
+        const short* hrow = a.h_prev + ((long long)d * a.B + (colok ? bcol : 0)) * H + fq * 8;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // eight k-steps of loads (24 x 16 bytes per lane) are issued before their MFMAs: the step is a latency
+        // chain, so it wants every load of a batch in flight at once
+        for (int ks0 = 0; ks0 < ksteps; ks0 += 8) {
+            bf16x8 wf[8], hh[8], hl[8];
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
+            for (int u = 0; u < 8; ++u) {
+                const int ks = ks0 + u < ksteps ? ks0 + u : ksteps - 1;     // clamp: in-range, result unused
+                wf[u] = *(const bf16x8*)(wrow + ks * 32);
+                hh[u] = *(const bf16x8*)(hrow + ks * 32);
+                hl[u] = *(const bf16x8*)(hrow + lo_off + ks * 32);
+            }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[bb][g] = 0.f;
-        for (int k = lane * 8; k < H; k += 512) {
-            bf16x8 wv[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) wv[g] = *(const bf16x8*)(w + (long long)g * H * H + k);
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                if (bb < nb) {
-                    const float* hp = a.h_prev + ((long long)d * a.B + b0 + bb) * H + k;
-                    const f32x4 h0 = *(const f32x4*)hp, h1 = *(const f32x4*)(hp + 4);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc[bb][g] = fmaf(h0[e], bf16_to_f32(wv[g][e]), acc[bb][g]);
-                            acc[bb][g] = fmaf(h1[e], bf16_to_f32(wv[g][4 + e]), acc[bb][g]);
-                        }
+            for (int u = 0; u < 8; ++u) {
+                if (ks0 + u < ksteps) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], hh[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], hl[u], acc, 0, 0, 0);
                 }
             }
         }
-        float mine[4] = {0.f, 0.f, 0.f, 0.f};                     // lane bb keeps batch row b0 + bb
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float tot = wave_sum(acc[bb][g]);
-                if (lane == bb) mine[g] = tot;
-            }
-        if (lane < nb) {
-            const int b = b0 + lane;
+        // lane (fr, fq) holds gates i, f, g, o of unit j0 + fq for batch row b0 + fr
+        if (colok) {
+            const int b = bcol, j = j0 + fq;
             const float* gx = a.gx + ((long long)b * a.T + t) * a.ld_gx + d * 4 * H + j;
-            const float gi = sigmoidf_(mine[0] + gx[0]);
-            const float gf = sigmoidf_(mine[1] + gx[H]);
-            const float gg = tanhf_(mine[2] + gx[2 * H]);
-            const float go = sigmoidf_(mine[3] + gx[3 * H]);
+            const float gi = sigmoidf_(acc[0] + gx[0]);
+            const float gf = sigmoidf_(acc[1] + gx[H]);
+            const float gg = tanhf_(acc[2] + gx[2 * H]);
+            const float go = sigmoidf_(acc[3] + gx[3 * H]);
             const long long si = ((long long)d * a.B + b) * H + j;
             const float cn = gf * a.c[si] + gi * gg;
             const float hn = go * tanhf_(cn);
             a.c[si] = cn;
-            a.h_next[si] = hn;
-            short* yr = a.y + ((long long)b * a.T + t) * a.ld_y + d * H + j;
             const short hi = f32_to_bf16(hn);
+            const short lo = f32_to_bf16(hn - bf16_to_f32(hi));
+            a.h_next[si] = hi;
+            a.h_next[si + lo_off] = lo;
+            short* yr = a.y + ((long long)b * a.T + t) * a.ld_y + d * H + j;
             yr[0] = hi;
-            if (a.split_y) yr[2 * H] = f32_to_bf16(hn - bf16_to_f32(hi));
+            if (a.split_y) yr[2 * H] = lo;
             if (a.ysum) a.ysum[(long long)b * 2 * H + d * H + j] += hn * a.ysum_scale;
         }
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,7 +329,7 @@ using namespace asl_detail;
 static int lstm_run(const asl_lstm_params* p, const float* gx, const void* w_hh, void* y_bf16, float* ysum,
                     float* state, hipStream_t s) {
     if (!p || !gx || !w_hh || !y_bf16 || !state) return ASL_EINVAL;
-    if (p->batch <= 0 || p->t <= 0 || p->hidden <= 0 || (p->hidden & 7)) return ASL_EINVAL;
+    if (p->batch <= 0 || p->t <= 0 || p->hidden <= 0 || (p->hidden & 31)) return ASL_EINVAL;
     if (p->ld_gx < 8 * p->hidden || p->ld_y < (p->split_y ? 4 : 2) * p->hidden) return ASL_EINVAL;
     if (((uintptr_t)w_hh & 15) || ((uintptr_t)state & 15)) return ASL_EINVAL;
     const long long n = 2LL * p->batch * p->hidden;           // elements of one [2][B][H] state array
@@ -343,16 +340,19 @@ static int lstm_run(const asl_lstm_params* p, const float* gx, const void* w_hh,
         e = hipMemsetAsync(ysum, 0, (size_t)n * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
-    LstmArgs a;
-    a.gx = gx; a.whh = (const short*)w_hh; a.c = state + 2 * n; a.y = (short*)y_bf16; a.ysum = ysum;
-    a.B = p->batch; a.T = p->t; a.H = p->hidden; a.ld_gx = p->ld_gx; a.ld_y = p->ld_y;
-    a.ysum_scale = p->ysum_scale; a.split_y = p->split_y;
-    const unsigned blocks = (unsigned)((2 * p->hidden + 3) / 4);      // one wave per (direction, unit)
-    for (int step = 0; step < p->t; ++step) {
-        a.h_prev = state + (step & 1) * n;
-        a.h_next = state + ((step + 1) & 1) * n;
-        a.step = step;
-        hipLaunchKernelGGL(lstm_step_kernel, dim3(blocks), dim3(256), 0, s, a);
+    {
+        // the two h arrays of `state` hold bf16 (hi | lo) planes of [2][B][H] each: 2*B*H floats' worth of bytes
+        LstmMfmaArgs m;
+        m.gx = gx; m.whh = (const short*)w_hh; m.c = state + 2 * n; m.y = (short*)y_bf16; m.ysum = ysum;
+        m.B = p->batch; m.T = p->t; m.H = p->hidden; m.ld_gx = p->ld_gx; m.ld_y = p->ld_y;
+        m.ysum_scale = p->ysum_scale; m.split_y = p->split_y;
+        const unsigned blocks = (unsigned)(2 * (p->hidden / 4));       // one wave per (direction, four units)
+        for (int step = 0; step < p->t; ++step) {
+            m.h_prev = (const short*)(state + (step & 1) * n);
+            m.h_next = (short*)(state + ((step + 1) & 1) * n);
+            m.step = step;
+            hipLaunchKernelGGL(lstm_step_mfma_kernel, dim3(blocks), dim3(64), 0, s, m);
+        }
     }
     return (int)hipGetLastError();
 }
