@@ -49,9 +49,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--clips", type=int, default=8, help="clips per GPU per step")
+    ap.add_argument("--clips", type=int, default=20, help="clips per GPU per step")
     ap.add_argument("--frames", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("ASL_CHUNK", "256")))
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("ASL_CHUNK", "640")),
+                    help="frames per backbone launch: 640 = 10 clips fills whole rounds of workgroups in every layer")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("ASL_STREAMS", "2")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dry-run", action="store_true",
@@ -130,11 +131,10 @@ def main():
         # event-bracketed serial pass (each conv launch alone on one stream) is kept as serial_*.
         achieved = flops_step / step_s / 1e12
         serial = flops_step / (conv_ms * 1e-3) / 1e12
-        chunks_per_step = -(-B * T // min(args.chunk, -(-B * T // max(1, args.streams))))
         ctr = profiled_counters()
         traffic = hbm_gbps = mfma_busy = None
         if ctr:
-            step_bytes = ctr["hbm_bytes_per_chunk"] * ctr.get("chunk_scale", 1.0) * chunks_per_step
+            step_bytes = ctr["hbm_bytes_per_chunk"] * (B * T / float(ctr.get("frames_per_chunk") or args.chunk))
             traffic = round(step_bytes / launches)
             hbm_gbps = round(step_bytes / step_s / 1e9, 1)
             mfma_busy = ctr.get("mfma_busy")

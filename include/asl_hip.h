@@ -120,6 +120,24 @@ int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, const void* 
                          const float* scale, const float* bias, const void* res, void* y,
                          asl_stream_t stream);
 
+/* A whole ResNet BasicBlock with 64 channels in and out, fused:
+ *     y = relu( bn2(conv2( relu(bn1(conv1(x))) )) + x ),   conv1, conv2 = nn.Conv2d(64, 64, 3, 1, 1, bias=False)
+ * (torchvision BasicBlock without downsample: conv1/bn1/relu/conv2/bn2, identity add, relu).  The intermediate
+ * activation is rounded to bf16 exactly as the two-launch form rounds it, but never leaves the chip.
+ * x: [n][h+2*in_halo][w+2*in_halo][64] (in_halo >= 1, zero halo), y: [n][h+2*out_halo][w+2*out_halo][64], y != x;
+ * w1, w2 packed as for asl_conv2d_nhwc_bf16 ([w_rows][9*64]); scale/bias fp32 [64] each, all required.
+ * n * (h+2*in_halo) * (w+2*in_halo) * 128 bytes must stay below 2 GiB per call (split the batch otherwise).
+ * channels other than 64: ASL_ENOTSUP. */
+typedef struct asl_block_params {
+    int32_t n, h, w, channels;
+    int32_t in_halo, out_halo;
+    int32_t w_rows;
+} asl_block_params;
+
+int asl_basic_block_c64_bf16(const asl_block_params* p, const void* x, const void* w1, const float* scale1,
+                             const float* bias1, const void* w2, const float* scale2, const float* bias2,
+                             void* y, asl_stream_t stream);
+
 /* First-layer convolution on packed RGB: nn.Conv2d(3, cout, (kh,kw), stride, pad) [+ BatchNorm2d
  * (eval)] [+ ReLU], e.g. the ResNet stem (7x7, stride 2, pad 3).  x is the packed clip tensor
  * written by asl_pack_clips / asl_preprocess_u8: [n][h+2*in_halo][w+2*in_halo][4] bf16 with
@@ -323,6 +341,7 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
  *   ASL_OP_PREPROCESS    NULL                    frames, y, clips_f32                    n, h0, w0, s, halo / mean[3], std[3]
  *   ASL_OP_MEAN_T        NULL                    x, y                                    rows, t, c
  *   ASL_OP_HEAD          NULL                    x, w, b, y                              m, f, c
+ *   ASL_OP_BASIC_BLOCK   asl_block_params*       x, w1, scale1, bias1, w2, scale2, bias2, y
  *
  * Returns ASL_OK, or the first failing op's return code with its index in *failed (if failed != NULL); ops
  * before it have been issued, ops after it have not.  ASL_EINVAL for an unknown kind, a stream index outside
@@ -330,14 +349,14 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
 enum {
     ASL_OP_CONV2D = 1, ASL_OP_STEM_CONV = 2, ASL_OP_STEM_POOL = 3, ASL_OP_CONV3D = 4, ASL_OP_LINEAR = 5,
     ASL_OP_MAXPOOL3D = 6, ASL_OP_MAXPOOL = 7, ASL_OP_AVGPOOL = 8, ASL_OP_PACK_CLIPS = 9, ASL_OP_PREPROCESS = 10,
-    ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12
+    ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12, ASL_OP_BASIC_BLOCK = 13
 };
 
 typedef struct asl_op {
     int32_t kind;
     int32_t stream;
     const void* params;
-    void* ptr[6];
+    void* ptr[8];
     int32_t i[8];
     float f[6];
 } asl_op;

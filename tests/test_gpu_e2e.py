@@ -141,6 +141,19 @@ def test_chunking_and_streams_do_not_change_results(gpu):
         del m
 
 
+def test_fused_basic_blocks_give_the_same_logits(gpu, monkeypatch):
+    """layer 1 run as one kernel per BasicBlock (opt-in) against the two-launch form and the oracle"""
+    om, m0 = _model("resnet18_mean")
+    monkeypatch.setenv("ASL_FUSE_BLOCKS", "1")
+    _, m1 = _model("resnet18_mean")
+    assert m1.fuse_blocks and not m0.fuse_blocks
+    clips = O.make_clips(2, 8, 224, 3)
+    y0, y1 = m0(clips.cuda()).cpu(), m1(clips.cuda()).cpu()
+    ref = om(clips)
+    assert rel_l2(y1, ref) <= REL_TOL and torch.equal(y1.argmax(1), ref.argmax(1))
+    assert rel_l2(y1, y0) <= 2e-4
+
+
 def test_single_frame_single_clip(gpu):
     """smallest clip the surface accepts: B=1, T=1"""
     om, m = _model("resnet18_mean")

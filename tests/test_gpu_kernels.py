@@ -151,6 +151,58 @@ def _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu, variant=0):
     assert torch.equal(y1, yd), "two launches on the same input differ"
 
 
+# fused 64-channel BasicBlock: strips of 7 rows on 56x56; a last strip shorter than the others; rows wider and
+# narrower than a 32-pixel tile; more strips than CUs (several per persistent workgroup); an image smaller than
+# one strip; output halo 0 and 2
+@pytest.mark.parametrize("n,h,w,out_halo", [(3, 56, 56, 1), (2, 30, 56, 1), (2, 28, 20, 0), (1, 5, 7, 2), (70, 56, 56, 1),
+                                            (4, 17, 100, 1)])
+def test_fused_basic_block_c64(gpu, n, h, w, out_halo):
+    from video_asl_recognition_amd import _lib as L
+    from video_asl_recognition_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(h * 7 + w)
+    x = _bf16(torch.randn(n, 64, h, w, generator=g))
+    w1 = _bf16(torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5)
+    w2 = _bf16(torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5)
+    s1, s2 = torch.empty(64).uniform_(0.5, 1.5, generator=g), torch.empty(64).uniform_(0.2, 0.6, generator=g)
+    b1, b2 = torch.empty(64).normal_(0, 0.1, generator=g), torch.empty(64).normal_(0, 0.1, generator=g)
+    v = lambda t: t.view(1, -1, 1, 1)
+    t = _bf16(F.relu(F.conv2d(x, w1, None, 1, 1) * v(s1) + v(b1)))       # the intermediate is a bf16 tensor
+    ref = F.relu(F.conv2d(t, w2, None, 1, 1) * v(s2) + v(b2) + x)
+    p1 = pack_conv(w1, "cuda", scale=s1.cuda(), bias=b1.cuda())
+    p2 = pack_conv(w2, "cuda", scale=s2.cuda(), bias=b2.cuda())
+    xd = _halo(x, 1)
+    oh = out_halo
+    yd = torch.full((n, h + 2 * oh, w + 2 * oh, 64), 5.0, dtype=torch.bfloat16, device="cuda")
+    p = L.BlockParams(n=n, h=h, w=w, channels=64, in_halo=1, out_halo=oh, w_rows=p1.w_rows)
+    args = (C.byref(p), _p(xd), _p(p1.w), _p(p1.scale), _p(p1.bias), _p(p2.w), _p(p2.scale), _p(p2.bias), _p(yd), None)
+    L.check(L.lib.asl_basic_block_c64_bf16(*args), "block")
+    torch.cuda.synchronize()
+    if oh:
+        assert bool((yd[:, :oh] == 5.0).all()) and bool((yd[:, :, -oh:] == 5.0).all()), "halo was written"
+    # two roundings in the chain, and y = conv + x may cancel: where the kernel's fp32 sum rounds an intermediate value
+    # to the other bf16 neighbour than torch's does, the output moves by a little more than its own ulp
+    got = _unhalo(yd, oh)
+    err = (got - _bf16(ref)).abs()
+    assert bool((err <= 2.0 ** -6 * ref.abs() + 2e-3).all()), f"max err {float(err.max()):.3e}"
+    assert float((err <= 2.0 ** -7 * ref.abs().clamp_min(1e-2)).float().mean()) > 0.999
+    y1 = yd.clone()
+    L.check(L.lib.asl_basic_block_c64_bf16(*args), "block")
+    torch.cuda.synchronize()
+    assert torch.equal(y1, yd), "two launches on the same input differ"
+    # against the two-launch form of the same block (same rounding points): at most 1 bf16 ulp apart
+    td = torch.zeros(n, h + 2, w + 2, 64, dtype=torch.bfloat16, device="cuda")
+    y2 = torch.zeros(n, h + 2, w + 2, 64, dtype=torch.bfloat16, device="cuda")
+    cp = L.Conv2dParams(n=n, h=h, w=w, cin=64, in_halo=1, cout=64, kh=3, kw=3, stride=1, pad=1, out_halo=1, out_ctot=64,
+                        out_coff=0, res_halo=1, res_ctot=64, res_coff=0, relu=1, w_rows=p1.w_rows)
+    L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(cp), _p(xd), _p(p1.w), _p(p1.scale), _p(p1.bias), None, _p(td), None))
+    L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(cp), _p(td), _p(p2.w), _p(p2.scale), _p(p2.bias), _p(xd), _p(y2), None))
+    torch.cuda.synchronize()
+    a_, b_ = _unhalo(yd, oh), _unhalo(y2, 1)
+    # same products, same rounding points: the two forms agree bit for bit on almost every element
+    d = (a_ - b_).abs()
+    assert bool((d <= 2.0 ** -6 * b_.abs() + 2e-3).all()) and float((d == 0).float().mean()) > 0.999
+
+
 def test_stem_conv_and_pack_clips(gpu):
     from video_asl_recognition_amd import _lib as L
     from video_asl_recognition_amd.packing import pack_stem

@@ -1,13 +1,33 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection CSVs per kernel: sum and per-launch mean of every
 counter.  HBM traffic per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE tallies
-128-byte read requests at 64 bytes, so wide coalesced reads are doubled; WRITE_SIZE is exact."""
+128-byte read requests at 64 bytes, so wide coalesced reads are doubled; WRITE_SIZE is exact.
+
+python tools/pmc_summary.py [--json out.json --frames-per-chunk N] a.csv b.csv ...
+With --json, also writes the figures bench.py reports next to its timing: HBM bytes of all path kernels
+(asl_detail::*) per chunk of frames -- total bytes / launches of the stem kernel, which runs once per chunk --
+and the MFMA-busy ratio of the conv kernels, SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x busy cycles), busy
+cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs)."""
 import csv
+import json
 import sys
 from collections import defaultdict
 
+CONV = ("stem_pool_kernel", "conv3x3_c64_kernel", "conv3x3_pp_kernel", "conv3x3_wide_kernel", "conv3x3_patch_kernel",
+        "gather_gemm_kernel")
 
-def main(paths):
+
+def main(argv):
+    json_out, fpc = None, None
+    paths = []
+    it = iter(argv)
+    for a in it:
+        if a == "--json":
+            json_out = next(it)
+        elif a == "--frames-per-chunk":
+            fpc = int(next(it))
+        else:
+            paths.append(a)
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(int))
     for p in paths:
@@ -18,14 +38,44 @@ def main(paths):
                 agg[k][c] += float(row["Counter_Value"])
                 calls[k][c] += 1
     print("kernel,counter,launches,sum,per_launch")
+    hbm = {}
     for k in sorted(agg):
         for c in sorted(agg[k]):
             n = calls[k][c]
             print(f"{k},{c},{n},{agg[k][c]:.6g},{agg[k][c] / n:.6g}")
         if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+            # the two counters come from separate passes of the same command: scale each to a per-launch figure
+            per = 2 * agg[k]["FETCH_SIZE"] / calls[k]["FETCH_SIZE"] + agg[k]["WRITE_SIZE"] / calls[k]["WRITE_SIZE"]
             n = calls[k]["FETCH_SIZE"]
-            kib = 2 * agg[k]["FETCH_SIZE"] + agg[k]["WRITE_SIZE"]
-            print(f"{k},HBM_BYTES_corrected,{n},{kib * 1024:.6g},{kib * 1024 / n:.6g}")
+            hbm[k] = (per * 1024, n)
+            print(f"{k},HBM_BYTES_corrected,{n},{per * 1024 * n:.6g},{per * 1024:.6g}")
+    if json_out:
+        stem = [k for k in hbm if "stem_pool_kernel" in k]
+        out = {"frames_per_chunk": fpc, "per_kernel": {}}
+        if stem:
+            chunks = hbm[stem[0]][1]
+            tot = sum(b * n for k, (b, n) in hbm.items() if "asl_detail" in k)
+            out["hbm_bytes_per_chunk"] = tot / chunks
+            out["chunks_profiled"] = chunks
+        busy = mf = 0.0
+        for k in agg:
+            rec = {}
+            if k in hbm:
+                rec["hbm_bytes_per_launch"] = hbm[k][0]
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in agg[k] and "GRBM_GUI_ACTIVE" in agg[k]:
+                cyc = agg[k]["GRBM_GUI_ACTIVE"] / 8.0
+                rec["mfma_busy"] = agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc) if cyc else None
+                if any(c in k for c in CONV):
+                    busy += cyc
+                    mf += agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"]
+            if rec and "asl_detail" in k:
+                out["per_kernel"][k] = rec
+        if busy:
+            out["mfma_busy"] = round(mf / (1024.0 * busy), 4)
+            out["mfma_busy_note"] = ("conv kernels, each profiled launch alone on the GPU (counter collection serialises "
+                                     "kernels): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)")
+        with open(json_out, "w") as f:
+            json.dump(out, f, indent=1)
 
 
 if __name__ == "__main__":

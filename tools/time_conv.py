@@ -30,6 +30,10 @@ SHAPES = [
     ("r18 3x3s2 128->256", 28, 128, 256, 3, 2, False),
     ("r18 3x3s2 256->512", 14, 256, 512, 3, 2, False),
     ("r50 3x3s2 128->128", 56, 128, 128, 3, 2, False),
+    ("r18 l1 3x3 64->64 +res", 56, 64, 64, 3, 1, True),
+    ("r18 l2 3x3 128->128 +res", 28, 128, 128, 3, 1, True),
+    ("r18 l3 3x3 256->256 +res", 14, 256, 256, 3, 1, True),
+    ("r18 l4 3x3 512->512 +res", 7, 512, 512, 3, 1, True),
 ]
 
 

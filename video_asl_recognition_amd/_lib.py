@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libaslhip.so")
+LIB_PATH = os.environ.get("ASL_LIB_PATH") or os.path.join(_HERE, "csrc", "libaslhip.so")   # override: diagnostic builds
 
 ASL_OK, ASL_EINVAL, ASL_ENOTSUP, ASL_ETOOBIG = 0, -1, -2, -3
 # kernel variants of asl_conv2d_nhwc_bf16 / asl_gather_gemm_bf16 (0 = the library chooses)
@@ -35,6 +35,10 @@ class Conv2dParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "h", "w", "cin", "in_halo", "cout", "kh", "kw", "stride", "pad",
         "out_halo", "out_ctot", "out_coff", "res_halo", "res_ctot", "res_coff", "relu", "w_rows", "variant")]
+
+
+class BlockParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "channels", "in_halo", "out_halo", "w_rows")]
 
 
 class StemParams(C.Structure):
@@ -68,12 +72,12 @@ class LstmParams(C.Structure):
 
 class Op(C.Structure):
     """asl_op: one launch as data, for asl_run_ops"""
-    _fields_ = [("kind", C.c_int32), ("stream", C.c_int32), ("params", C.c_void_p), ("ptr", C.c_void_p * 6),
+    _fields_ = [("kind", C.c_int32), ("stream", C.c_int32), ("params", C.c_void_p), ("ptr", C.c_void_p * 8),
                 ("i", C.c_int32 * 8), ("f", C.c_float * 6)]
 
 
 (OP_CONV2D, OP_STEM_CONV, OP_STEM_POOL, OP_CONV3D, OP_LINEAR, OP_MAXPOOL3D, OP_MAXPOOL, OP_AVGPOOL, OP_PACK_CLIPS,
- OP_PREPROCESS, OP_MEAN_T, OP_HEAD) = range(1, 13)
+ OP_PREPROCESS, OP_MEAN_T, OP_HEAD, OP_BASIC_BLOCK) = range(1, 14)
 
 
 class AttnParams(C.Structure):
@@ -94,6 +98,7 @@ _PROTOS = {
     "asl_strerror": ([C.c_int], C.c_char_p),
     "asl_gather_gemm_bf16": ([C.POINTER(GemmParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_conv2d_nhwc_bf16": ([C.POINTER(Conv2dParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_basic_block_c64_bf16": ([C.POINTER(BlockParams)] + [_P] * 9, C.c_int),
     "asl_stem_conv_bf16": ([C.POINTER(StemParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_stem_pool_bf16": ([C.POINTER(StemPoolParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_conv3d_ndhwc_bf16": ([C.POINTER(Conv3dParams), _P, _P, _P, _P, _P, _P], C.c_int),

@@ -186,6 +186,11 @@ extern "C" int asl_run_ops(const asl_op* ops, int count, const asl_stream_t* str
                     rc = asl_head_f32((const float*)p[0], i[0], i[1], (const float*)p[1], (const float*)p[2], i[2],
                                       (float*)p[3], s);
                     break;
+                case ASL_OP_BASIC_BLOCK:
+                    rc = asl_basic_block_c64_bf16((const asl_block_params*)o.params, p[0], p[1], (const float*)p[2],
+                                                  (const float*)p[3], p[4], (const float*)p[5], (const float*)p[6],
+                                                  p[7], s);
+                    break;
                 default:
                     rc = ASL_EINVAL;
             }

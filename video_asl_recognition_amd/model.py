@@ -84,6 +84,9 @@ class AslClipModel:
         # diagnostics / A-B runs: force one conv kernel variant (L.CONV_*), run stem and max-pool unfused
         self.conv_variant = int(os.environ.get("ASL_CONV_VARIANT", "0"))
         self.fused_stem = not os.environ.get("ASL_NO_FUSED_STEM")
+        # one kernel per 64-channel BasicBlock (asl_basic_block_c64_bf16) instead of two conv launches: half the HBM
+        # traffic of layer 1, measured at parity end to end, so the two-launch form stays the default
+        self.fuse_blocks = os.environ.get("ASL_FUSE_BLOCKS", "0") == "1"
         self._w: Dict[str, PackedConv] = {}
         self._fc_w = self._fc_b = None
         self._temporal = None
@@ -190,7 +193,14 @@ class AslClipModel:
             for prefix, cin, planes, stride, ds in resnet_blocks(spec.backbone):
                 oh, ow = x.h // stride, x.w // stride
                 w = self._w
-                if basic:
+                if basic and self.fuse_blocks and not ds and stride == 1 and cin == planes == 64:
+                    # both convs of the block in one kernel: the intermediate activation stays on the chip
+                    c1, c2 = w[prefix + ".conv1"], w[prefix + ".conv2"]
+                    y = pool.get(oh, ow, planes)
+                    bp = L.BlockParams(n=0, h=x.h, w=x.w, channels=64, in_halo=x.halo, out_halo=y.halo, w_rows=c1.w_rows)
+                    add(L.OP_BASIC_BLOCK, bp, (x.t, c1.w, c1.scale, c1.bias, c2.w, c2.scale, c2.bias, y.t), conv=True,
+                        keep=(x, y, c1, c2))
+                elif basic:
                     t = pool.get(oh, ow, planes)
                     conv_op(w[prefix + ".conv1"], x, t, stride, 1, True)
                     idt = x
