@@ -151,7 +151,7 @@ def test_fused_basic_blocks_give_the_same_logits(gpu, monkeypatch):
     y0, y1 = m0(clips.cuda()).cpu(), m1(clips.cuda()).cpu()
     ref = om(clips)
     assert rel_l2(y1, ref) <= REL_TOL and torch.equal(y1.argmax(1), ref.argmax(1))
-    assert rel_l2(y1, y0) <= 2e-4
+    assert rel_l2(y1, y0) <= 5e-4       # different summation order inside the MFMAs: a few bf16 roundings flip
 
 
 def test_single_frame_single_clip(gpu):
