@@ -275,6 +275,25 @@ def test_clip_stream_equals_direct_classification(gpu):
     assert list(clipio.ClipStream(m)([])) == []
 
 
+def test_clip_stream_and_label_map_against_the_oracle(gpu, tmp_path):
+    """streamed host batches -> top-k -> gloss strings, checked against the CPU oracle's classify_clip (not against
+    the HIP path itself): indices identical, probabilities within 1e-3, decoded glosses those of the oracle's indices"""
+    import json
+    from video_asl_recognition_amd import clipio
+    om, m = _model("resnet18_mean")
+    batches = [O.make_frames(2, 4, 60, 80, seed=s) for s in (20, 21)] + [O.make_frames(1, 4, 60, 80, seed=22)]
+    path = tmp_path / "labels.json"
+    path.write_text(json.dumps([{"gloss": f"sign_{i:03d}", "instances": []} for i in range(100)]))
+    labels = clipio.LabelMap.from_json(str(path), num_classes=100)
+    for batch, (idx, prob) in zip(batches, clipio.ClipStream(m, topk=3)(batches)):
+        ri, rp = O.classify_clip(om, batch, topk=3, size=224)
+        assert torch.equal(idx.cpu(), ri)
+        torch.testing.assert_close(prob.cpu(), rp, rtol=1e-3, atol=1e-5)
+        decoded = labels.decode(idx, prob)
+        assert [[g for g, _ in row] for row in decoded] == [[f"sign_{i:03d}" for i in row] for row in ri.tolist()]
+        assert all(abs(p - q) < 1e-3 for row, ref in zip(decoded, rp.tolist()) for (_, p), q in zip(row, ref))
+
+
 def test_clip_stream_survives_shape_changes_while_batches_are_in_flight(gpu):
     """batch shapes change in both directions mid-stream (buffers regrown while the previous batch's
     kernels are still queued): every result still equals the direct classification of that batch"""

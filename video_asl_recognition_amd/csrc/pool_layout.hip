@@ -212,20 +212,15 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
         const long long n = t / a.od;
         const short* src = a.x + n * a.in_sn + (long long)d * a.sd * a.in_sd + (long long)h * a.sh * a.in_sh +
                            (long long)w * a.sw * a.in_sw + a.in_off0 + 8 * c;
-        float m[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = 0.f;     // inputs are >= 0 and every window holds a real cell
+        // inputs are >= 0 (post-ReLU) and every window holds a real cell: non-negative bf16 values order like their
+        // bit patterns read as signed 16-bit integers (and -0.0 reads as the most negative one), so the max runs
+        // on the packed pairs directly (v_pk_max_i16: two channels per instruction, no unpacking), starting from 0
+        bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int kd = 0; kd < a.kd; ++kd)
-            for (int kh = 0; kh < a.kh; ++kh)
-                for (int kw = 0; kw < a.kw; ++kw) {
-                    const bf16x8 v = *(const bf16x8*)(src + (long long)kd * a.in_sd + (long long)kh * a.in_sh +
-                                                      (long long)kw * a.in_sw);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], bf16_to_f32(v[e]));
-                }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(m[e]);
+            for (int kh = 0; kh < a.kh; ++kh) {
+                const short* row = src + (long long)kd * a.in_sd + (long long)kh * a.in_sh;
+                for (int kw = 0; kw < a.kw; ++kw) o = __builtin_elementwise_max(o, *(const bf16x8*)(row + (long long)kw * a.in_sw));
+            }
         *(bf16x8*)(a.y + n * a.out_sn + (long long)d * a.out_sd + (long long)h * a.out_sh + (long long)w * a.out_sw +
                    a.out_off0 + 8 * c) = o;
     }
