@@ -127,11 +127,16 @@ int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, const void* 
  * x: [n][h+2*in_halo][w+2*in_halo][64] (in_halo >= 1, zero halo), y: [n][h+2*out_halo][w+2*out_halo][64], y != x;
  * w1, w2 packed as for asl_conv2d_nhwc_bf16 ([w_rows][9*64]); scale/bias fp32 [64] each, all required.
  * n * (h+2*in_halo) * (w+2*in_halo) * 128 bytes must stay below 2 GiB per call (split the batch otherwise).
- * channels other than 64: ASL_ENOTSUP. */
+ * channels other than 64: ASL_ENOTSUP.
+ * variant: 0 picks the kernel; ASL_BLOCK_PAIRED = eight waves per workgroup, four running conv1 one step ahead of
+ * the four running conv2 (one filter bank per wave); ASL_BLOCK_SOLO = four waves that each hold both banks and run
+ * the convs one after the other.  A forced variant that does not fit the shape: ASL_ENOTSUP. */
+enum { ASL_BLOCK_AUTO = 0, ASL_BLOCK_SOLO = 1, ASL_BLOCK_PAIRED = 2 };
 typedef struct asl_block_params {
     int32_t n, h, w, channels;
     int32_t in_halo, out_halo;
     int32_t w_rows;
+    int32_t variant;
 } asl_block_params;
 
 int asl_basic_block_c64_bf16(const asl_block_params* p, const void* x, const void* w1, const float* scale1,

@@ -34,7 +34,7 @@ def test_version_and_strerror():
 
 def test_struct_sizes_match_header_layout():
     from video_asl_recognition_amd import _lib as L
-    assert C.sizeof(L.Geom) == 24
+    assert C.sizeof(L.Geom) == 24 and C.sizeof(L.BlockParams) == 8 * 4
     assert C.sizeof(L.Conv2dParams) == 19 * 4
     assert C.sizeof(L.StemParams) == 12 * 4
     assert C.sizeof(L.Conv3dParams) == 21 * 4

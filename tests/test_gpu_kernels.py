@@ -156,7 +156,8 @@ def _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu, variant=0):
 # one strip; output halo 0 and 2
 @pytest.mark.parametrize("n,h,w,out_halo", [(3, 56, 56, 1), (2, 30, 56, 1), (2, 28, 20, 0), (1, 5, 7, 2), (70, 56, 56, 1),
                                             (4, 17, 100, 1)])
-def test_fused_basic_block_c64(gpu, n, h, w, out_halo):
+@pytest.mark.parametrize("variant", [1, 2], ids=["solo", "paired"])
+def test_fused_basic_block_c64(gpu, n, h, w, out_halo, variant):
     from video_asl_recognition_amd import _lib as L
     from video_asl_recognition_amd.packing import pack_conv
     g = torch.Generator().manual_seed(h * 7 + w)
@@ -173,7 +174,7 @@ def test_fused_basic_block_c64(gpu, n, h, w, out_halo):
     xd = _halo(x, 1)
     oh = out_halo
     yd = torch.full((n, h + 2 * oh, w + 2 * oh, 64), 5.0, dtype=torch.bfloat16, device="cuda")
-    p = L.BlockParams(n=n, h=h, w=w, channels=64, in_halo=1, out_halo=oh, w_rows=p1.w_rows)
+    p = L.BlockParams(n=n, h=h, w=w, channels=64, in_halo=1, out_halo=oh, w_rows=p1.w_rows, variant=variant)
     args = (C.byref(p), _p(xd), _p(p1.w), _p(p1.scale), _p(p1.bias), _p(p2.w), _p(p2.scale), _p(p2.bias), _p(yd), None)
     L.check(L.lib.asl_basic_block_c64_bf16(*args), "block")
     torch.cuda.synchronize()

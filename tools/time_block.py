@@ -25,12 +25,12 @@ def main():
                      bias=torch.randn(64).cuda() * 0.1) for _ in range(2)]
     t = torch.zeros_like(x)
     y = torch.zeros_like(x)
-    bp = L.BlockParams(n=n, h=h, w=w, channels=64, in_halo=1, out_halo=1, w_rows=pcs[0].w_rows)
+    bps = {v: L.BlockParams(n=n, h=h, w=w, channels=64, in_halo=1, out_halo=1, w_rows=pcs[0].w_rows, variant=v) for v in (1, 2)}
     cp = L.Conv2dParams(n=n, h=h, w=w, cin=64, in_halo=1, cout=64, kh=3, kw=3, stride=1, pad=1, out_halo=1, out_ctot=64,
                         out_coff=0, res_halo=1, res_ctot=64, res_coff=0, relu=1, w_rows=pcs[0].w_rows)
 
-    def fused():
-        L.check(L.lib.asl_basic_block_c64_bf16(C.byref(bp), P(x), P(pcs[0].w), P(pcs[0].scale), P(pcs[0].bias), P(pcs[1].w),
+    def fused(v):
+        L.check(L.lib.asl_basic_block_c64_bf16(C.byref(bps[v]), P(x), P(pcs[0].w), P(pcs[0].scale), P(pcs[0].bias), P(pcs[1].w),
                                                P(pcs[1].scale), P(pcs[1].bias), P(y), None))
 
     def two():
@@ -38,7 +38,9 @@ def main():
         L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(cp), P(t), P(pcs[1].w), P(pcs[1].scale), P(pcs[1].bias), P(x), P(y), None))
 
     flops = 2 * 2.0 * n * h * w * 64 * 576
-    for name, f in (("two launches", two), ("fused", fused), ("two launches", two), ("fused", fused)):
+    solo, paired = (lambda: fused(1)), (lambda: fused(2))
+    for name, f in (("two launches", two), ("fused solo", solo), ("fused paired", paired), ("two launches", two),
+                    ("fused solo", solo), ("fused paired", paired)):
         for _ in range(3):
             f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -38,7 +38,7 @@ class Conv2dParams(C.Structure):
 
 
 class BlockParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "channels", "in_halo", "out_halo", "w_rows")]
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "channels", "in_halo", "out_halo", "w_rows", "variant")]
 
 
 class StemParams(C.Structure):

@@ -27,6 +27,7 @@
 #include "asl_hip.h"
 #include "common.h"
 #include "patch_args.h"
+#include "block_mfma.h"
 
 #ifndef ASL_BLOCK_EXP
 #define ASL_BLOCK_EXP 0        // diagnostic builds: 1 = K loop without its LDS reads, 2 = without its MFMAs (results wrong)
@@ -53,43 +54,6 @@ struct BlockArgs {
     int out_sh;                    // output row stride, elements (pixel stride is 64)
     FastDiv dW;
 };
-
-__device__ __forceinline__ int img_addr(int p) { return ((p >> 4) << 11) | ((p & 15) << 4); }
-
-// One 32-pixel x 32-channel tile of a 3x3 convolution over a chunk-major LDS image: 36 K steps of 16
-// channels.  `u` is the image pixel of the lane's top-left tap, `lds` the image's LDS byte address plus
-// the lane's k-half * 256.
-// The K loop is written as inline assembly: the wave is alone on its SIMD, so nothing else hides an LDS read's
-// latency or an instruction's issue slot, and at one wave per SIMD every vector instruction that does not fit
-// beside an MFMA's 32 cycles is paid in full.  Fragments are read kAhead steps ahead of the MFMA that consumes
-// them (LDS operations return in order, so "all but the N youngest" is the wait); the second filter bank is
-// addressed in the accumulation registers directly (`a` operands) instead of being copied out before every use.
-// The assembler-level hazards the compiler cannot see are covered by hand and sit inside the MFMA's own asm
-// statement, where no compiler-inserted copy can slip past them: kEdge 1 = first MFMA of a tile (two wait
-// states after the accumulator was zeroed), 2 = last (18 wait states before its result may be read).
-#define ASL_MFMA_FIRST "s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0"
-#define ASL_MFMA_BODY "s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
-#define ASL_MFMA_LAST "s_waitcnt lgkmcnt(%4)\n\tv_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\ts_nop 15\n\ts_nop 3"
-// kEdge 1: first MFMA of a chain (accumulates onto the constant 0: no register to clear), 2: last MFMA of the tile
-template <bool kBankInAgprs, int kWait, int kEdge>
-__device__ __forceinline__ void mfma_step(f32x16& acc, f32x16& other, const bf16x8& w, const bf16x8& x) {
-    if constexpr (kBankInAgprs) {
-        if constexpr (kEdge == 1) asm volatile(ASL_MFMA_FIRST : "=&v"(acc) : "a"(w), "v"(x), "n"(kWait));
-        else if constexpr (kEdge == 2) asm volatile(ASL_MFMA_LAST : "+v"(acc), "+v"(other) : "a"(w), "v"(x), "n"(kWait));
-        else asm volatile(ASL_MFMA_BODY : "+v"(acc) : "a"(w), "v"(x), "n"(kWait));
-    } else {
-        if constexpr (kEdge == 1) asm volatile(ASL_MFMA_FIRST : "=&v"(acc) : "v"(w), "v"(x), "n"(kWait));
-        else if constexpr (kEdge == 2) asm volatile(ASL_MFMA_LAST : "+v"(acc), "+v"(other) : "v"(w), "v"(x), "n"(kWait));
-        else asm volatile(ASL_MFMA_BODY : "+v"(acc) : "v"(w), "v"(x), "n"(kWait));
-    }
-}
-
-template <int kOff>
-__device__ __forceinline__ bf16x8 lds_frag(unsigned ad) {
-    bf16x8 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(ad), "n"(kOff));
-    return v;
-}
 
 // The epilogue of a tile (16 values per lane: BatchNorm, residual or row mask, ReLU, bf16, two 16-byte stores)
 // is cut into slices -- a pair of values each, then the two stores -- that ride between the MFMAs of the NEXT
@@ -364,11 +328,16 @@ extern "C" int asl_basic_block_c64_bf16(const asl_block_params* p, const void* x
     if (!p || !x || !w1 || !w2 || !scale1 || !bias1 || !scale2 || !bias2 || !y) return ASL_EINVAL;
     if (p->n <= 0 || p->h <= 0 || p->w <= 0 || p->in_halo < 1 || p->out_halo < 0) return ASL_EINVAL;
     if (p->channels != 64) return ASL_ENOTSUP;
-    if (p->w_rows < 64) return ASL_EINVAL;
+    if (p->w_rows < 64 || p->variant < 0 || p->variant > ASL_BLOCK_PAIRED) return ASL_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w2 & 15) || ((uintptr_t)y & 15) ||
         ((uintptr_t)scale1 & 15) || ((uintptr_t)bias1 & 15) || ((uintptr_t)scale2 & 15) || ((uintptr_t)bias2 & 15))
         return ASL_EINVAL;
     if (x == y) return ASL_EINVAL;                          // strips re-read rows that other strips have already replaced
+    if (p->variant != ASL_BLOCK_SOLO) {
+        const int e = try_launch_block_c64_pair(p, x, w1, scale1, bias1, w2, scale2, bias2, y, (hipStream_t)stream);
+        if (e != -1) return e;
+        if (p->variant == ASL_BLOCK_PAIRED) return ASL_ENOTSUP;
+    }
     BlockArgs a;
     a.x = (const char*)x; a.w1 = (const char*)w1; a.w2 = (const char*)w2; a.y = (char*)y;
     a.s1 = scale1; a.b1 = bias1; a.s2 = scale2; a.b2 = bias2;

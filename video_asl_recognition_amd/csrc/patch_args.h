@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "asl_hip.h"
 #include "common.h"
 
 namespace asl_detail {
@@ -46,5 +47,8 @@ int try_launch_conv3x3_pp(PatchArgs a, int n, hipStream_t stream);
 // persistent 64 -> 64 channel kernel (conv3x3_c64.hip): returns -1 when the request does not fit it
 int try_launch_conv3x3_c64(PatchArgs a, int n, hipStream_t stream);
 int launch_conv3x3_patch(PatchArgs a, hipStream_t stream);
+// producer / consumer form of the fused 64-channel BasicBlock (block_c64_pair.hip): -1 when the shape does not fit it
+int try_launch_block_c64_pair(const asl_block_params* p, const void* x, const void* w1, const float* scale1, const float* bias1,
+                              const void* w2, const float* scale2, const float* bias2, void* y, hipStream_t stream);
 
 }  // namespace asl_detail
