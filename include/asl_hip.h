@@ -126,7 +126,7 @@ int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, const void* 
  * activation is rounded to bf16 exactly as the two-launch form rounds it, but never leaves the chip.
  * x: [n][h+2*in_halo][w+2*in_halo][64] (in_halo >= 1, zero halo), y: [n][h+2*out_halo][w+2*out_halo][64], y != x;
  * w1, w2 packed as for asl_conv2d_nhwc_bf16 ([w_rows][9*64]); scale/bias fp32 [64] each, all required.
- * n * (h+2*in_halo) * (w+2*in_halo) * 128 bytes must stay below 2 GiB per call (split the batch otherwise).
+ * (ASL_BLOCK_SOLO only: n * (h+2*in_halo) * (w+2*in_halo) * 128 bytes must stay below 2 GiB per call.)
  * channels other than 64: ASL_ENOTSUP.
  * variant: 0 picks the kernel; ASL_BLOCK_PAIRED = eight waves per workgroup, four running conv1 one step ahead of
  * the four running conv2 (one filter bank per wave); ASL_BLOCK_SOLO = four waves that each hold both banks and run

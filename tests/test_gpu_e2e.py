@@ -142,10 +142,10 @@ def test_chunking_and_streams_do_not_change_results(gpu):
 
 
 def test_fused_basic_blocks_give_the_same_logits(gpu, monkeypatch):
-    """layer 1 run as one kernel per BasicBlock (opt-in) against the two-launch form and the oracle"""
-    om, m0 = _model("resnet18_mean")
-    monkeypatch.setenv("ASL_FUSE_BLOCKS", "1")
-    _, m1 = _model("resnet18_mean")
+    """layer 1 run as one kernel per BasicBlock (the default) against the two-launch form and the oracle"""
+    om, m1 = _model("resnet18_mean")
+    monkeypatch.setenv("ASL_FUSE_BLOCKS", "0")
+    _, m0 = _model("resnet18_mean")
     assert m1.fuse_blocks and not m0.fuse_blocks
     clips = O.make_clips(2, 8, 224, 3)
     y0, y1 = m0(clips.cuda()).cpu(), m1(clips.cuda()).cpu()

@@ -28,6 +28,10 @@
 #include "common.h"
 #include "patch_args.h"
 
+#ifndef ASL_PAIR_EXP
+#define ASL_PAIR_EXP 0
+#endif
+
 namespace asl_detail {
 
 struct PairArgs {
@@ -60,7 +64,11 @@ struct PairSteps {
     // fragments are addressed in the former, the last four in the latter.
     static constexpr int kBankA = 32;
     __device__ static __forceinline__ void read(bf16x8 (&xf)[kRing], const unsigned (&ad)[9]) {
+#if ASL_PAIR_EXP == 1      // diagnostic build: K loop without its LDS reads (results wrong)
+        asm volatile("" : "=v"(xf[S % kRing]) : "v"(ad[S >> 2]));
+#else
         xf[S % kRing] = lds_frag<(S & 3) * 512>(ad[S >> 2]);
+#endif
     }
     __device__ static __forceinline__ void run(f32x16 (&acc)[2], const bf16x8 (&w)[36], bf16x8 (&xf)[kRing], const unsigned (&ad)[9]) {
         constexpr int inflight = 35 - S < kAhead - 1 ? 35 - S : kAhead - 1;      // reads younger than step S's
@@ -90,8 +98,13 @@ __device__ __forceinline__ void pair_finish(const f32x16& acc, const float* bnl,
     f32x4 sc[4], bi[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+#if ASL_PAIR_EXP == 2      // diagnostic build: no BatchNorm reads (results wrong)
+        sc[g] = f32x4{1.f, 1.f, 1.f, 1.f};
+        bi[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
         sc[g] = *(const f32x4*)(bnl + 4 * g);
         bi[g] = *(const f32x4*)(bnl + 64 + 4 * g);
+#endif
     }
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -147,25 +160,40 @@ __global__ __launch_bounds__(512, 1) void block_c64_pair_kernel(const PairArgs a
         c0 = (unit - img * a.ncs) * CW;
     };
 
-    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)a.x_bytes, 0x00020000);
-    constexpr unsigned kOob = 0x80000000u;
     const int xpieces = a.xpix >> 3;                       // 1 KiB pieces: 16 pixels x 4 chunks
-    // x image of step g (rows kR .. kR+R+1, columns c0-2 .. c0+CW+1 of the image) into x buffer g & 1; producers only.
     // Piece j: pixel group j >> 1, chunks 4*(j & 1) .. +3; lane -> pixel 16*(j >> 1) + lane % 16, chunk 4*(j & 1) + lane / 16.
-    auto dma_step = [&](int g) {
+    // Source of step g's x image: a buffer descriptor based at its image (wave-uniform, scalar work only), so lane
+    // offsets are 32-bit whatever the batch size, and rows past the end of the tensor read as zeros by the
+    // descriptor's own range check.  p0 = first pixel of the x image within the halo'd image.
+    struct StepSrc {
+        __amdgpu_buffer_rsrc_t rs;
+        int p0;
+    };
+    auto dma_source = [&](int g) -> StepSrc {
         int img, c0, k;
         decode(g, img, c0, k);
-        const long long P0 = ((long long)img * a.Hp + (k * R + a.in_halo)) * Wp + (c0 - 2 + a.in_halo);
-        char* const dst = smem + (g & 1) * xbytes;
-        for (int j = wr; j < xpieces; j += 4) {
-            const int px = 16 * (j >> 1) + (lane & 15);
-            const int i = (int)fdiv((unsigned)px, a.dXW), jc = px - i * XW;
-            const long long off = (P0 + (long long)i * Wp + jc) * 128 + (4 * (j & 1) + (lane >> 4)) * 16;
-            const unsigned vo = (off < 0 || off >= a.x_bytes) ? kOob : (unsigned)off;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, vo, 0, 0, 0);
-        }
+        const long long base = (long long)img * a.Hp * Wp * 128;
+        const long long rem = a.x_bytes - base;
+        StepSrc s;
+        s.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + base), 0, (unsigned)(rem > 0x7fffffffLL ? 0x7fffffffLL : rem), 0x00020000);
+        s.p0 = (k * R + a.in_halo) * Wp + (c0 - 2 + a.in_halo);      // >= Wp - 1: never before the image
+        return s;
+    };
+    auto dma_piece = [&](int j, const StepSrc& src, char* dst) {
+        const int px = 16 * (j >> 1) + (lane & 15);
+        const int i = (int)fdiv((unsigned)px, a.dXW), jc = px - i * XW;
+        const unsigned vo = (unsigned)(src.p0 + i * Wp + jc) * 128u + (4 * (j & 1) + (lane >> 4)) * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rs, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, vo, 0, 0, 0);
     };
 
+#if defined(ASL_PAIR_STAMPS)   // diagnostic build: s_memtime stamps of workgroup 0's waves 0 and 4 into y's first halo row
+    unsigned long long* const stamp = (unsigned long long*)a.y + 400 * role;
+    int stamp_i = 0;
+    if (blockIdx.x == 0 && lane == 0) ((unsigned long long*)a.y)[800 + wave] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+#define STAMP() do { if (blockIdx.x == 0 && wr == 0 && lane == 0 && stamp_i < 400) stamp[stamp_i] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
     const int pitch = role ? TW : XW;                      // the image this wave's taps walk over
     unsigned tapenc[9];                                    // wave-uniform
 #pragma unroll
@@ -176,37 +204,72 @@ __global__ __launch_bounds__(512, 1) void block_c64_pair_kernel(const PairArgs a
     const unsigned khalf = (unsigned)lh << 8;
     const int chl = 32 * wc + 16 * lh;                     // the lane's 16 output channels
 
-    if (G > 0 && role == 0) dma_step(0);
+    if (role == 0) {
+        const StepSrc src = dma_source(0);
+        for (int j = wr; j < xpieces; j += 4) dma_piece(j, src, smem);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // The bank has arrived: said here, by a use of every fragment, or the compiler retires the 36 loads lazily
+    // inside the tile loops with counted waits that would then also wait for every later DMA piece, residual load
+    // and store.
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+        if (s < PairSteps<0>::kBankA) asm volatile("" : "+a"(w[s]));
+        else asm volatile("" : "+v"(w[s]));
+    }
     const float* const bnl = bn + 128 * role + chl;        // the lane's scale values, bias 64 floats on
 
     for (int g = 0; g <= G; ++g) {
         if (role == 0) {
+            STAMP();
             if (g < G) {
-                if (g + 1 < G) dma_step(g + 1);
+                // the next step's x image: this wave's pieces go out a few ahead of each tile, not in one burst
+                const bool more = g + 1 < G;
+                const StepSrc nsrc = dma_source(more ? g + 1 : g);
+                char* const ndst = smem + ((g + 1) & 1) * xbytes;
+#if ASL_PAIR_EXP == 3      // diagnostic build: no x image DMA after the first (results wrong)
+                int jn = xpieces;
+#else
+                int jn = more ? wr : xpieces;
+#endif
+                STAMP();
                 int img, c0, k;
                 decode(g, img, c0, k);
                 char* const tb = smem + 2 * xbytes + (g & 1) * tbytes;
                 const char* const tprev = smem + 2 * xbytes + ((g & 1) ^ 1) * tbytes;
                 // local t rows 0, 1: above the image when k = 0 (row 0 = zeros; row 1 is computed below), otherwise
                 // the previous step's last two rows
+#if ASL_PAIR_EXP == 4      // diagnostic build: no carry copy (results wrong)
+                if (false) {
+                } else if (k == 0) {
+#else
                 if (k == 0) {
+#endif
                     for (int i = tid; i < TW * 8; i += 256) *(i32x4*)(tb + img_addr(i >> 3) + (i & 7) * 256) = i32x4{0, 0, 0, 0};
-                } else {
+                } else if (ASL_PAIR_EXP != 4) {
                     for (int i = tid; i < 2 * TW * 8; i += 256)
                         *(i32x4*)(tb + img_addr(i >> 3) + (i & 7) * 256) = *(const i32x4*)(tprev + img_addr(R * TW + (i >> 3)) + (i & 7) * 256);
                 }
+                STAMP();
                 const int r_first = k == 0 ? 1 : 2;
-                const int n1 = (R + 2 - r_first) * TW;     // pixel slots: rows r_first .. R+1, all TW columns
-                const int t1 = (n1 + 31) >> 5;
+                // Pixel slots run over rows of XW, the x image's own pitch (the last XW - TW of a row are idle): the 16
+                // lanes of an LDS pass then read 16 consecutive image pixels, which the chunk-major image serves without
+                // a bank conflict; rows of TW slots would put a two-pixel jump inside most passes.
+                const int n1 = (R + 2 - r_first) * XW;
+                const int t1 = ASL_PAIR_EXP == 5 ? 0 : (n1 + 31) >> 5;    // 5: diagnostic build, producers idle
+                const int my_tiles = (t1 - wq + 1) >> 1 > 0 ? (t1 - wq + 1) >> 1 : 1;
+                const int per_tile = ((xpieces + 3) / 4 + my_tiles - 1) / my_tiles;
                 const unsigned xl = lds0 + (g & 1) * xbytes;
                 const unsigned zad = (lds0 + zoff) | khalf;
                 const bf16x8 nores[2] = {};
                 for (int tile = wq; tile < t1; tile += 2) {
+                    for (int q = 0; q < per_tile && jn < xpieces; ++q, jn += 4) dma_piece(jn, nsrc, ndst);
                     int m = tile * 32 + lp;
-                    const bool slot_ok = m < n1;
-                    m = slot_ok ? m : n1 - 1;
-                    const int rt = (int)fdiv((unsigned)m, a.dTW), ct = m - rt * TW;
+                    m = m < n1 ? m : n1 - 1;
+                    const int rt = (int)fdiv((unsigned)m, a.dXW);
+                    int ct = m - rt * XW;
+                    const bool slot_ok = tile * 32 + lp < n1 && ct < TW;
+                    ct = ct < TW ? ct : TW - 1;            // idle slots repeat the row's last pixel
                     const int lr = r_first + rt;           // local t row: image row kR - 1 + lr
                     // t (lr, ct) reads x local rows lr-2 .. lr, columns ct .. ct+2
                     const int umid = (lr - 1) * XW + ct;
@@ -228,23 +291,39 @@ __global__ __launch_bounds__(512, 1) void block_c64_pair_kernel(const PairArgs a
                         *(i32x4*)dst = i32x4{(int)out[0], (int)out[1], (int)out[2], (int)out[3]};
                         *(i32x4*)(dst + 256) = i32x4{(int)out[4], (int)out[5], (int)out[6], (int)out[7]};
                     }
+                    STAMP();
                 }
+                for (; jn < xpieces; jn += 4) dma_piece(jn, nsrc, ndst);
             }
+            STAMP();
             // the next x image has landed, this step's t image is written
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
+            STAMP();
             if (g >= 1) {
                 const int gc = g - 1;
                 int img, c0, k;
                 decode(gc, img, c0, k);
                 const unsigned tl = lds0 + 2 * xbytes + (gc & 1) * tbytes;
+#if defined(ASL_PAIR_WIDE_SLOTS)
+                const int n2 = R * TW;                     // slot rows at the t image's pitch: conflict-free reads, (TW - CW) idle slots a row
+#else
                 const int n2 = R * CW;
-                const int t2 = (n2 + 31) >> 5;
+#endif
+                const int t2 = ASL_PAIR_EXP == 6 ? 0 : (n2 + 31) >> 5;    // 6: diagnostic build, consumers idle
                 for (int tile = wq; tile < t2; tile += 2) {
                     int m = tile * 32 + lp;
+#if defined(ASL_PAIR_WIDE_SLOTS)
+                    m = m < n2 ? m : n2 - 1;
+                    const int ro = (int)fdiv((unsigned)m, a.dTW);
+                    int co = m - ro * TW;
+                    const bool slot_ok = tile * 32 + lp < n2 && co < CW;
+                    co = co < CW ? co : CW - 1;
+#else
                     const bool slot_ok = m < n2;
                     m = slot_ok ? m : n2 - 1;
                     const int ro = (int)fdiv((unsigned)m, a.dCW), co = m - ro * CW;
+#endif
                     const int yo = k * R + ro, xo = c0 + co;
                     const bool ok = slot_ok && yo < a.H && xo < a.W;
                     const char* rp = a.x + 2 * ((((long long)img * a.Hp + (ok ? yo : 0) + a.in_halo) * Wp + (ok ? xo : 0) + a.in_halo) * 64 + chl);
@@ -264,8 +343,10 @@ __global__ __launch_bounds__(512, 1) void block_c64_pair_kernel(const PairArgs a
                         *(i32x4*)dst = i32x4{(int)out[0], (int)out[1], (int)out[2], (int)out[3]};
                         *(i32x4*)(dst + 16) = i32x4{(int)out[4], (int)out[5], (int)out[6], (int)out[7]};
                     }
+                    STAMP();
                 }
             }
+            STAMP();
             // this step's reads of the t image are over (the stores to y need no wait)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -283,7 +364,7 @@ int try_launch_block_c64_pair(const asl_block_params* p, const void* x, const vo
     a.Wp = p->w + 2 * p->in_halo; a.Hp = p->h + 2 * p->in_halo;
     a.wk = 9 * 64;
     a.x_bytes = 2LL * p->n * a.Hp * a.Wp * 64;
-    if (a.x_bytes >= 0x7fffffffLL) return ASL_EINVAL;      // 32-bit LDS-DMA offsets: split the batch
+    if ((long long)a.Hp * a.Wp >= (1LL << 23)) return -1;  // 32-bit byte offsets within one image
     const int owp = p->w + 2 * p->out_halo, ohp = p->h + 2 * p->out_halo;
     a.out_sn = (long long)ohp * owp * 64; a.out_sh = owp * 64;
     // the fewest column strips whose images leave room for steps of at least min(8, h) rows

@@ -85,8 +85,8 @@ class AslClipModel:
         self.conv_variant = int(os.environ.get("ASL_CONV_VARIANT", "0"))
         self.fused_stem = not os.environ.get("ASL_NO_FUSED_STEM")
         # one kernel per 64-channel BasicBlock (asl_basic_block_c64_bf16) instead of two conv launches: half the HBM
-        # traffic of layer 1, measured at parity end to end, so the two-launch form stays the default
-        self.fuse_blocks = os.environ.get("ASL_FUSE_BLOCKS", "0") == "1"
+        # traffic of layer 1; ASL_FUSE_BLOCKS=0 keeps the two-launch form
+        self.fuse_blocks = os.environ.get("ASL_FUSE_BLOCKS", "1") == "1"
         self._w: Dict[str, PackedConv] = {}
         self._fc_w = self._fc_b = None
         self._temporal = None
