@@ -157,7 +157,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}, all-gather of logits"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "the conv MFMA kernels of one step (stem_pool, conv3x3_c64, conv3x3_pp / conv3x3_wide, "
+                "kernel": "the conv MFMA kernels of one step (stem_pool, block_c64_pair, conv3x3_pp / conv3x3_wide, "
                           "gather_gemm), as scheduled in the timed region",
                 "achieved": round(achieved, 2),
                 "peak": MFMA_PEAK_TFLOPS,
@@ -245,10 +245,6 @@ def dry_run(args, world, rank):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-CONV_KERNELS = ("stem_pool_kernel", "conv3x3_c64_kernel", "conv3x3_pp_kernel", "conv3x3_wide_kernel", "conv3x3_patch_kernel",
-                "gather_gemm_kernel")
 
 
 def profiled_counters():

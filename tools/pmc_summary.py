@@ -13,7 +13,7 @@ import json
 import sys
 from collections import defaultdict
 
-CONV = ("stem_pool_kernel", "conv3x3_c64_kernel", "conv3x3_pp_kernel", "conv3x3_wide_kernel", "conv3x3_patch_kernel",
+CONV = ("stem_pool_kernel", "block_c64_pair_kernel", "block_c64_kernel", "conv3x3_c64_kernel", "conv3x3_pp_kernel", "conv3x3_wide_kernel", "conv3x3_patch_kernel",
         "gather_gemm_kernel")
 
 
