@@ -258,6 +258,34 @@ def test_maxpool_exact(gpu):
     assert torch.equal(_unhalo(yd, 1), ref)
 
 
+# I3D's pools (3x3x3/s2 p1, 1x3x3/(1,2,2), 3x3x3/s1 p1 inside the Mixed blocks, 2x2x2/s2) on ragged sizes, plus a window
+# no fixed-size kernel takes (the generic loop)
+@pytest.mark.parametrize("k,s,p,shape", [((3, 3, 3), (2, 2, 2), (1, 1, 1), (2, 8, 14, 18, 64)),
+                                         ((1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 5, 28, 26, 64)),
+                                         ((3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 4, 14, 14, 192)),
+                                         ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 3, 7, 9, 32)),
+                                         ((2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 14, 14, 832)),
+                                         ((2, 3, 2), (1, 2, 1), (0, 1, 0), (1, 4, 9, 7, 16))])
+def test_maxpool3d_exact(gpu, k, s, p, shape):
+    from video_asl_recognition_amd import _lib as L
+    n, d, h, w, c = shape
+    g = torch.Generator().manual_seed(d * 100 + w)
+    x = _bf16(torch.rand(n, c, d, h, w, generator=g) * 4)
+    ref = F.max_pool3d(x, k, s, p)
+    od, oh, ow = ref.shape[2:]
+    hd, hh = p[0], max(p[1], p[2])
+    xd = torch.zeros(n, d + 2 * hd, h + 2 * hh, w + 2 * hh, c, dtype=torch.bfloat16, device="cuda")
+    xd[:, hd:hd + d, hh:hh + h, hh:hh + w] = x.permute(0, 2, 3, 4, 1).to(torch.bfloat16).cuda()
+    yd = torch.full((n, od + 2, oh + 2, ow + 2, c), 9.0, dtype=torch.bfloat16, device="cuda")
+    pp = L.Pool3dParams(n=n, d=d, h=h, w=w, c=c, in_halo_d=hd, in_halo=hh, kd=k[0], kh=k[1], kw=k[2], sd=s[0], sh=s[1], sw=s[2],
+                        pd=p[0], ph=p[1], pw=p[2], out_halo_d=1, out_halo=1)
+    L.check(L.lib.asl_maxpool3d_ndhwc(C.byref(pp), _p(xd), _p(yd), None))
+    torch.cuda.synchronize()
+    got = yd[:, 1:-1, 1:-1, 1:-1].permute(0, 4, 1, 2, 3).float().cpu()
+    assert torch.equal(got, ref)
+    assert bool((yd[:, 0] == 9.0).all()) and bool((yd[:, :, :, -1] == 9.0).all()), "halo was written"
+
+
 @pytest.mark.parametrize("c", [64, 512, 2048])
 def test_avgpool_mean_head(gpu, c):
     from video_asl_recognition_amd import _lib as L

@@ -226,6 +226,65 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
     }
 }
 
+int grid_for(long long total);
+
+// The same for the window sizes the models use, known at compile time: a lane produces WPT neighbouring outputs of
+// a row for its 8 channels.  Every input column the lane needs is reduced over the window's (kd, kh) rows once and
+// shared by the outputs it belongs to (3x3x3 / stride 1, four outputs: 54 loads instead of 108), and the output
+// index is split with multiply-high divisions instead of 64-bit ones.
+template <int KD, int KH, int KW, int SW, int WPT>
+__global__ __launch_bounds__(256) void maxpool_fixed_kernel(const PoolArgs a, const FastDiv dC8, const FastDiv dWG, const FastDiv dOH,
+                                                            const FastDiv dOD, const int wgroups) {
+    constexpr int NCOL = (WPT - 1) * SW + KW;
+    const unsigned total = (unsigned)a.n * a.od * a.oh * wgroups * a.c8;       // < 2^31, checked by the host
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        unsigned t = fdiv(i, dC8);
+        const int c = (int)(i - t * a.c8);
+        unsigned q = fdiv(t, dWG);
+        const int w0 = (int)(t - q * wgroups) * WPT;
+        t = q; q = fdiv(t, dOH);
+        const int h = (int)(t - q * a.oh);
+        t = q; q = fdiv(t, dOD);
+        const int d = (int)(t - q * a.od);
+        const long long n = q;
+        const short* src = a.x + n * a.in_sn + (long long)d * a.sd * a.in_sd + (long long)h * a.sh * a.in_sh +
+                           (long long)w0 * SW * a.in_sw + a.in_off0 + 8 * c;
+        const int nout = a.ow - w0 < WPT ? a.ow - w0 : WPT;                    // outputs of this lane that exist
+        const int ncol = (nout - 1) * SW + KW;                                 // columns they read
+        bf16x8 col[NCOL];
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) col[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                const short* row = src + (long long)kd * a.in_sd + (long long)kh * a.in_sh;
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j)
+                    if (j < KW || j < ncol) col[j] = __builtin_elementwise_max(col[j], *(const bf16x8*)(row + (long long)j * a.in_sw));
+            }
+        short* dst = a.y + n * a.out_sn + (long long)d * a.out_sd + (long long)h * a.out_sh + (long long)w0 * a.out_sw + a.out_off0 + 8 * c;
+#pragma unroll
+        for (int o = 0; o < WPT; ++o) {
+            bf16x8 m = col[o * SW];
+#pragma unroll
+            for (int kw = 1; kw < KW; ++kw) m = __builtin_elementwise_max(m, col[o * SW + kw]);
+            if (o < nout) *(bf16x8*)(dst + (long long)o * a.out_sw) = m;
+        }
+    }
+}
+
+template <int KD, int KH, int KW, int SW, int WPT>
+static int launch_maxpool_fixed(const PoolArgs& a, hipStream_t stream) {
+    const int wgroups = (a.ow + WPT - 1) / WPT;
+    const long long total = (long long)a.n * a.od * a.oh * wgroups * a.c8;
+    if (total >= 0x7fffffffLL) return -1;
+    hipLaunchKernelGGL((maxpool_fixed_kernel<KD, KH, KW, SW, WPT>), dim3(grid_for(total)), dim3(256), 0, stream, a,
+                       make_fastdiv((unsigned)a.c8), make_fastdiv((unsigned)wgroups), make_fastdiv((unsigned)a.oh),
+                       make_fastdiv((unsigned)a.od), wgroups);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 // per-frame spatial mean: halo'd NHWC bf16 -> fp32 [n][c] (+ bf16 copy)
 // block = one frame; lane layout (pixel slice, 8-channel chunk)
@@ -461,6 +520,12 @@ extern "C" int asl_maxpool3d_ndhwc(const asl_pool3d_params* p, const void* x, vo
     a.out_sw = p->c; a.out_sh = owp * p->c; a.out_sd = ohp * owp * p->c;
     a.out_sn = (long long)odp * ohp * owp * p->c;
     a.out_off0 = p->out_halo_d * a.out_sd + p->out_halo * a.out_sh + p->out_halo * a.out_sw;
+    int e = -1;
+    if (a.kd == 3 && a.kh == 3 && a.kw == 3 && a.sw == 1) e = launch_maxpool_fixed<3, 3, 3, 1, 4>(a, (hipStream_t)stream);
+    else if (a.kd == 3 && a.kh == 3 && a.kw == 3 && a.sw == 2) e = launch_maxpool_fixed<3, 3, 3, 2, 2>(a, (hipStream_t)stream);
+    else if (a.kd == 1 && a.kh == 3 && a.kw == 3 && a.sw == 2) e = launch_maxpool_fixed<1, 3, 3, 2, 2>(a, (hipStream_t)stream);
+    else if (a.kd == 2 && a.kh == 2 && a.kw == 2 && a.sw == 2) e = launch_maxpool_fixed<2, 2, 2, 2, 2>(a, (hipStream_t)stream);
+    if (e != -1) return e;
     const long long total = (long long)a.n * a.od * a.oh * a.ow * a.c8;
     hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
