@@ -55,6 +55,17 @@ __device__ __forceinline__ float row_shl(float v) {
                                                                  0x100 + N, 0xf, 0xf, false));
 }
 
+// max of a lane's value and those of the next two lanes of its 16-lane row, for values >= 0 (lanes past the row's
+// end read as 0): the shifts ride on the max instructions' own operand, two instructions in all
+__device__ __forceinline__ float row_max3(float v) {
+    float m;
+    // (two wait states between a vector write of a register and its use as a DPP operand: the compiler does not
+    // see into the asm, so they are spelled out)
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(m) : "v"(v));
+    asm("v_max_f32_dpp %0, %1, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(m) : "v"(v));
+    return m;
+}
+
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) char lds[2 * kPatchStride];
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolArgs a)
         const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;    // first conv pixel of the tile (may be -1)
         const char* patch = lds + buf * kPatchStride;
         const int cx = cx0 + fr;
-        const bool col_in = cx >= 0 && cx < a.CW;
+        const bool col_in = (cx >= 0 && cx < a.CW) || fr == 15;   // lane 15's column feeds no pooled pixel of this tile
 
         f32x4 pa[4], pb[4];                                 // running vertical max of pooled rows 2w, 2w+1
 #pragma unroll
@@ -152,14 +163,29 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolArgs a)
             }
             const int cy = cy0 + cr;
             const bool inside = col_in && cy >= 0 && cy < a.CH;
+            // The running maxima start at 0, so max(p, v) already is max(p, relu(v)).  Only tiles on the image's top
+            // and left edge hold conv pixels outside it (whose value must not count): every other tile takes the
+            // branch-free path with no select per value.
+            if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = acc[j] * sc[j] + bi[j];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = inside ? fmaxf(acc[j][e] * sc[j][e] + bi[j][e], 0.f) : 0.f;
-                    if (c <= 2) pa[j][e] = fmaxf(pa[j][e], v);
-                    if (c >= 2) pb[j][e] = fmaxf(pb[j][e], v);
+                    for (int e = 0; e < 4; ++e) {
+                        if (c <= 2) pa[j][e] = fmaxf(pa[j][e], v[e]);
+                        if (c >= 2) pb[j][e] = fmaxf(pb[j][e], v[e]);
+                    }
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = inside ? acc[j][e] * sc[j][e] + bi[j][e] : 0.f;
+                        if (c <= 2) pa[j][e] = fmaxf(pa[j][e], v);
+                        if (c >= 2) pb[j][e] = fmaxf(pb[j][e], v);
+                    }
+            }
         }
         // ---- horizontal max over conv columns 2lx, 2lx+1, 2lx+2 -> even lanes fr = 2lx hold pooled column lx --
 #pragma unroll
@@ -173,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = half ? pb[j][e] : pa[j][e];
-                    o[e] = f32_to_bf16(fmaxf(v, fmaxf(row_shl<1>(v), row_shl<2>(v))));
+                    o[e] = f32_to_bf16(row_max3(v));
                 }
                 if (store) *(bf16x4*)(dst + j * 32) = o;
             }
