@@ -1,6 +1,6 @@
 # diagnostic: LDS / MFMA counters of the fused-block timing run
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r2i/pmc_block
 mkdir -p $O
 cd $R

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_i3d
 rm -rf $O; mkdir -p $O
 cd $R
