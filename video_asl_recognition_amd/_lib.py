@@ -89,6 +89,11 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
         "(or __graft_entry__.build()); this package has no non-HIP fallback")
 
+# torch first: its wheel carries its own libamdhip64.so.7, and the HIP runtime this library binds to must be the one
+# torch's streams and allocations live in.  Loaded the other way round, the process ends up with two HIP runtimes
+# (the system one for these kernels, the wheel's for torch) and launches fail with "no ROCm-capable device".
+import torch  # noqa: E402,F401
+
 lib = C.CDLL(LIB_PATH)
 
 _P, _I, _F3 = C.c_void_p, C.c_int, C.POINTER(C.c_float)

@@ -59,7 +59,10 @@ struct PairArgs {
 
 template <int S>
 struct PairSteps {
-    static constexpr int kAhead = 5, kRing = kAhead + 1;
+#ifndef ASL_PAIR_AHEAD
+#define ASL_PAIR_AHEAD 5
+#endif
+    static constexpr int kAhead = ASL_PAIR_AHEAD, kRing = kAhead + 1;
     // At two waves per SIMD a wave has 128 accumulation registers and 128 ordinary ones: 32 of the bank's 36
     // fragments are addressed in the former, the last four in the latter.
     static constexpr int kBankA = 32;
@@ -84,8 +87,10 @@ __device__ __forceinline__ f32x16 pair_tile(const bf16x8 (&w)[36], const unsigne
     PairSteps<0>::read(xf, ad);
     PairSteps<1>::read(xf, ad);
     PairSteps<2>::read(xf, ad);
-    PairSteps<3>::read(xf, ad);
-    PairSteps<4>::read(xf, ad);
+    if constexpr (PairSteps<0>::kAhead > 3) PairSteps<3>::read(xf, ad);
+    if constexpr (PairSteps<0>::kAhead > 4) PairSteps<4>::read(xf, ad);
+    if constexpr (PairSteps<0>::kAhead > 5) PairSteps<5>::read(xf, ad);
+    static_assert(PairSteps<0>::kAhead >= 3 && PairSteps<0>::kAhead <= 6, "prefetch distance");
     f32x16 acc[2];
     PairSteps<0>::run(acc, w, xf, ad);
     return acc[0] + acc[1];
