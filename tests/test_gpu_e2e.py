@@ -123,6 +123,23 @@ def test_full_size_linearity_property(gpu):
     torch.testing.assert_close(m(clips[:, perm]), y, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("name,B,T,sub", [("i3d", 16, 64, 3), ("resnet50_bilstm", 16, 64, 5), ("twostream_transformer", 8, 128, 3)])
+def test_full_batch_logits_do_not_depend_on_the_batch(gpu, name, B, T, sub):
+    """Size-independent check at the configurations' full batch and clip length (too slow for the CPU oracle):
+    a clip's logits are the same whether it travels in the full batch or in ragged sub-batches of `sub` clips --
+    the clip axis of the 3-D backbone, the batch rows of the recurrence's MFMA groups (16 at a time), the attention
+    workgroups and every GEMM's row tiling must all keep clips apart."""
+    from video_asl_recognition_amd import AslClipModel
+    m = AslClipModel(name, seed=5)
+    clips = O.make_clips(B, T, m.spec.size, 21).cuda()
+    kp = O.make_keypoints(B, T, 21).cuda() if m.spec.keypoints else None
+    y = m(clips, kp).clone()
+    assert y.shape == (B, m.spec.num_classes) and bool(torch.isfinite(y).all())
+    parts = [m(clips[i:i + sub], None if kp is None else kp[i:i + sub]).clone() for i in range(0, B, sub)]
+    torch.testing.assert_close(torch.cat(parts), y, rtol=1e-5, atol=1e-5)
+    assert float((y[0] - y[1]).abs().max()) > 0                                  # clips do get different logits
+
+
 def test_chunking_and_streams_do_not_change_results(gpu):
     """Ragged chunking over two streams (300 frames as 128 + 128 + 44), one stream, and one big chunk give the
     same per-frame features bit for bit: every output pixel is computed by the same K-ordered sum whatever tile,
