@@ -8,11 +8,11 @@ For N>1 the command may be started either way: under torch.distributed.run (WORL
 environment: this process is one rank), or bare -- then this process touches no GPU, starts the N
 ranks itself through torch.distributed.run on 127.0.0.1, and exits with their return code.
 
-A step = one forward() over one batch of `--clips` clips per GPU (pack -> stem -> maxpool ->
-20 convs -> avg-pool -> mean over T -> head) plus, for N>1, the RCCL all-gather of the logits.
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the gather-GEMM conv
-kernel, all of its launches in a step) against the dense bf16 MFMA peak; `cpu_baseline` is the
-PyTorch-CPU-eager oracle timed on this host's cores (rank 0, N=1 only).
+A step = one forward() over one batch of `--clips` clips per GPU (pack -> fused stem + max-pool ->
+layer 1 as two fused BasicBlocks -> the 15 convs of layers 2-4 -> avg-pool -> mean over T -> head) plus,
+for N>1, the RCCL all-gather of the logits.  Rank 0 prints ONE JSON line.  `roofline` prices the conv
+kernels (all of their launches in a step, as scheduled) against the dense bf16 MFMA peak; `cpu_baseline`
+is the PyTorch-CPU-eager oracle timed on this host's cores (rank 0, N=1 only).
 """
 import argparse
 import json
