@@ -282,14 +282,23 @@ __global__ __launch_bounds__(512, 1) void block_c64_pair_kernel(const PairArgs a
                     const unsigned emid = xl + (unsigned)img_addr(umid) + 0x700u;
                     const unsigned etop = xl + (unsigned)img_addr(top ? umid - XW : 0) + 0x700u;
                     unsigned ad[9];
+#if ASL_PAIR_EXP == 8      // diagnostic build: no per-tile address arithmetic (results wrong)
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) ad[i] = (xl + tapenc[i] + lp * 16) | khalf;
+#else
 #pragma unroll
                     for (int i = 0; i < 3; ++i) ad[i] = top ? (((etop + tapenc[i]) & ~0x700u) | khalf) : zad;
 #pragma unroll
                     for (int i = 0; i < 6; ++i) ad[3 + i] = ((emid + tapenc[i]) & ~0x700u) | khalf;
+#endif
                     const f32x16 acc = pair_tile(w, ad);
                     const int yt = k * R - 1 + lr, xt = c0 - 1 + ct;
                     const bool inside = yt >= 0 && yt < a.H && xt >= 0 && xt < a.W;   // outside: conv2's zero padding
                     unsigned out[8];
+#if ASL_PAIR_EXP == 7      // diagnostic build: no tile epilogue (results wrong)
+                    asm volatile("" :: "v"(acc));
+                    continue;
+#endif
                     pair_finish<false>(acc, bnl, nores, inside, out);
                     char* const dst = tb + img_addr(lr * TW + ct) + (chl >> 3) * 256;
                     if (slot_ok) {
@@ -338,9 +347,17 @@ __global__ __launch_bounds__(512, 1) void block_c64_pair_kernel(const PairArgs a
                     const unsigned e0 = tl + (unsigned)img_addr(ro * TW + co) + 0x700u;
                     unsigned ad[9];
 #pragma unroll
+#if ASL_PAIR_EXP == 8
+                    for (int i = 0; i < 9; ++i) ad[i] = (tl + tapenc[i] + lp * 16) | khalf;
+#else
                     for (int i = 0; i < 9; ++i) ad[i] = ((e0 + tapenc[i]) & ~0x700u) | khalf;
+#endif
                     const f32x16 acc = pair_tile(w, ad);
                     unsigned out[8];
+#if ASL_PAIR_EXP == 7
+                    asm volatile("" :: "v"(acc), "v"(res[0]), "v"(res[1]));
+                    continue;
+#endif
                     pair_finish<true>(acc, bnl, res, true, out);
                     char* const dst = a.y + 2 * ((long long)img * a.out_sn + (long long)((ok ? yo : 0) + a.out_halo) * a.out_sh +
                                                  (long long)((ok ? xo : 0) + a.out_halo) * 64 + chl);
