@@ -100,3 +100,20 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "asl_oracle" not in src and "np_restatement" not in src, f
+
+
+def test_one_hip_runtime_in_the_process():
+    """Loading the library before torch used to leave two HIP runtimes in the process (the system one for these
+    kernels, the torch wheel's for torch): kernel launches then failed with 'no ROCm-capable device'.  Whatever is
+    imported first, exactly one libamdhip64 may be mapped."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from video_asl_recognition_amd import _lib\n"
+            "import torch\n"
+            "paths = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}\n"
+            "print(len(paths), sorted(paths))\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "1", out.stdout
