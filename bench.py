@@ -81,15 +81,11 @@ def main():
     spec = SPECS["resnet18_mean"]
     B, T, S = args.clips, args.frames, spec.size
     model = AslClipModel(spec, device=str(dev), frames_per_chunk=args.chunk, streams=args.streams)
+    # the product path takes its weights from its own initialiser on every rank; the oracle is built (with the same
+    # values) only for the cpu_baseline leg, after the timed region
     use_oracle = rank == 0 and world == 1 and not args.no_cpu_baseline
-    oracle = None
-    if use_oracle:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import asl_oracle as O
-        oracle = O.build("resnet18_mean", seed=0)
-        model.load_state_dict(oracle.state_dict())
-    else:
-        model.load_state_dict(init_state_dict(spec, seed=0))
+    state = init_state_dict(spec, seed=0)
+    model.load_state_dict(state)
 
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     clips = torch.randn(B, T, 3, S, S, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
@@ -100,7 +96,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -131,13 +127,27 @@ def main():
         # event-bracketed serial pass (each conv launch alone on one stream) is kept as serial_*.
         achieved = flops_step / step_s / 1e12
         serial = flops_step / (conv_ms * 1e-3) / 1e12
+        # counters cannot be read inside the timed run: they come from the newest committed summary of this same
+        # command, and are reported only when that summary was collected on these kernel sources with this chunking
         ctr = profiled_counters()
         traffic = hbm_gbps = mfma_busy = None
+        profiled = {"source": None, "counters_stale": None}
         if ctr:
-            step_bytes = ctr["hbm_bytes_per_chunk"] * (B * T / float(ctr.get("frames_per_chunk") or args.chunk))
-            traffic = round(step_bytes / launches)
-            hbm_gbps = round(step_bytes / step_s / 1e9, 1)
-            mfma_busy = ctr.get("mfma_busy")
+            from video_asl_recognition_amd._lib import source_hash
+            nstreams = max(1, min(args.streams, -(-B * T // args.chunk)))
+            run_chunk = min(args.chunk, -(-B * T // nstreams))          # frames per launch in this run (model._run_backbone)
+            same_cfg = ctr.get("frames_per_chunk") == run_chunk
+            stale = ctr.get("source_hash") != source_hash()
+            profiled = {"source": ctr["file"], "collected_on_source_hash": ctr.get("source_hash"),
+                        "this_source_hash": source_hash(), "counters_stale": bool(stale),
+                        "frames_per_chunk": ctr.get("frames_per_chunk"), "same_chunking": bool(same_cfg),
+                        "note": ctr["note"]}
+            if same_cfg and not stale:
+                step_bytes = ctr["hbm_bytes_per_chunk"] * (B * T / float(ctr["frames_per_chunk"]))
+                traffic = round(step_bytes / launches)
+                hbm_gbps = round(step_bytes / step_s / 1e9, 1)
+                mfma_busy = ctr.get("mfma_busy")
+        pre = time_with_preprocess(model, B, T, args.steps, args.warmup, dev)
         result = {
             "metric": "clips/sec end-to-end (T=64, 224x224, bf16)",
             "value": round(clips_per_s, 2),
@@ -164,7 +174,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic,
-                "traffic_note": (ctr or {}).get("note", "no committed counter summary found"),
+                "profiled": profiled,
                 "hbm_gbps": hbm_gbps,
                 "hbm_peak_gbps": HBM_PEAK_GBPS,
                 "hbm_frac": None if hbm_gbps is None else round(hbm_gbps / HBM_PEAK_GBPS, 4),
@@ -176,27 +186,53 @@ def main():
                 "serial_avg_launch_us": round(conv_ms * 1e3 / launches, 2),
             },
         }
+        result["with_preprocess"] = pre
         if use_oracle:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import asl_oracle as O
+            oracle = O.build("resnet18_mean", seed=0)
+            oracle.load_state_dict(state, strict=False)
             result["cpu_baseline"], result["parity"] = cpu_baseline(oracle, model, T, S)
+        # the line goes out before the process group is torn down: a hang or error in the teardown cannot lose it
         print(json.dumps(result), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
 def launch_ranks(n: int) -> int:
     """Start `n` ranks of this script (one per GPU) under torch.distributed.run and return their exit
-    code.  Runs before anything in this process has touched a GPU; the ranks are child processes."""
+    code.  Runs before anything in this process has touched a GPU; the ranks are child processes.  The ranks'
+    stdout is passed through untouched (rank 0's JSON line); their stderr is passed through too and also kept
+    per rank, so that when the job fails the last lines of every rank's stderr are printed once more, rank by rank."""
+    import glob
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    with tempfile.TemporaryDirectory(prefix="asl_bench_ranks_") as logdir:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "--tee", "2", "--log-dir", logdir,
+               os.path.abspath(__file__)] + sys.argv[1:]
+        rc = subprocess.run(cmd, env=env).returncode
+        if rc != 0:
+            print(f"bench.py: the {n} ranks exited with code {rc}; last lines of each rank's stderr:", file=sys.stderr)
+            for path in sorted(glob.glob(os.path.join(logdir, "**", "stderr.log"), recursive=True)):
+                try:
+                    with open(path, errors="replace") as f:
+                        tail = f.read().splitlines()[-25:]
+                except OSError:
+                    continue
+                rank_dir = os.path.basename(os.path.dirname(path))
+                print(f"--- rank {rank_dir} ({len(tail)} lines) ---", file=sys.stderr)
+                for ln in tail:
+                    print("  " + ln, file=sys.stderr)
+            sys.stderr.flush()
+    return rc
 
 
 def dry_run(args, world, rank):
@@ -260,12 +296,33 @@ def profiled_counters():
     try:
         with open(paths[-1]) as f:
             d = json.load(f)
+        d["file"] = os.path.basename(paths[-1])
         d["note"] = (f"HBM bytes per conv launch = profiled (2*FETCH_SIZE + WRITE_SIZE) KiB of all kernels of a "
                      f"{d.get('frames_per_chunk', '?')}-frame chunk x chunks per step / conv launches "
                      f"({os.path.basename(paths[-1])})")
         return d
     except (OSError, ValueError, KeyError):
         return None
+
+
+def time_with_preprocess(model, B, T, steps, warmup, dev, h0=240, w0=320):
+    """The second figure: the same step fed with uint8 frames (h0 x w0, resident in HBM) instead of normalised clips --
+    bilinear resize + normalise + pack in one kernel, then the same backbone and head, then softmax / top-5
+    (classify_clip).  Timed after the headline region, same fences, this rank only."""
+    g = torch.Generator(device=dev).manual_seed(7)
+    frames = torch.randint(0, 256, (B, T, h0, w0, 3), generator=g, device=dev, dtype=torch.uint8)
+    for _ in range(max(1, warmup)):
+        model.classify_clip(frames, topk=5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        idx, _ = model.classify_clip(frames, topk=5)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert idx.shape == (B, 5)
+    return {"value": round(B / dt, 2), "unit": "clips/s", "ms_per_step": round(dt * 1e3, 3), "scope": "this rank",
+            "input": f"uint8 frames [{B},{T},{h0},{w0},3] resident in HBM -> resize + normalise -> backbone -> "
+                     f"mean over T -> head -> softmax / top-5"}
 
 
 def time_conv_launches(model, clips, passes=3):

@@ -271,7 +271,8 @@ int asl_softmax_topk(const float* logits, int m, int c, int k, int64_t* idx, flo
  * index, in [H,2H); if split_y, additionally bf16(h - bf16(h)) in columns [2H,4H), the low halves for
  * a split-precision GEMM operand) and, if ysum != NULL, ysum fp32 [batch][2H] = sum over t of ysum_scale * h (the
  * temporal mean when ysum_scale = 1/t).  state: caller scratch of 6*batch*H floats (h ping, h pong, c; zeroed here).
- * H must be a multiple of 32.  h is carried between steps as a bf16 pair (hi + lo, ~16 mantissa bits), W_hh h runs
+ * H must be a multiple of 32 (other multiples of 8 return ASL_ENOTSUP: the recurrence kernel steps K by 32; anything
+ * else ASL_EINVAL).  h is carried between steps as a bf16 pair (hi + lo, ~16 mantissa bits), W_hh h runs
  * on the matrix cores with fp32 accumulation, gates and the cell state are fp32; one launch per time step on
  * `stream`. */
 typedef struct asl_lstm_params {

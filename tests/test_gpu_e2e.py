@@ -239,18 +239,33 @@ def test_twostream_transformer_matches_oracle(gpu):
         m(clips.cuda())
 
 
-@pytest.mark.parametrize("T,tol", [(64, REL_TOL), (16, 2e-3)])
-def test_i3d_matches_oracle(gpu, T, tol):
-    """The 1e-3 bar is stated at the config's T=64.  A 16-frame clip leaves 2x7x7 positions for the final
-    average instead of 8x7x7, so the per-activation bf16 rounding (2^-9) averages down ~2x less: 2e-3."""
+def _i3d_case(T):
     om, m = _model("i3d", frames_per_chunk=64)
     g = np.load(os.path.join(GOLDEN, f"i3d_fwd_b1t{T}s224.npz"))
     clips = O.make_clips(1, T, 224, 0)
     y = m(clips.cuda()).cpu()
     ref = torch.from_numpy(g["logits"])
     assert y.shape == (1, 100)
-    assert rel_l2(y, ref) <= tol, rel_l2(y, ref)
     assert torch.equal(y.argmax(1), ref.argmax(1))
+    return rel_l2(y, ref)
+
+
+def test_i3d_matches_oracle(gpu):
+    """The configuration's own clip length, T = 64: logits within 1e-3 of the fp32 oracle, arg-max identical."""
+    rel = _i3d_case(64)
+    assert rel <= REL_TOL, rel
+
+
+I3D_SHORT_CLIP_TOL = 2e-3
+
+
+def test_i3d_short_clip_out_of_config_T16(gpu):
+    """OUT OF CONFIG: a 16-frame clip is not a length any configuration names (the I3D configuration is T = 64).  It
+    leaves 2x7x7 positions for the final average instead of 8x7x7, so the per-activation bf16 rounding averages down
+    about half as much and the logits land at 1.4e-3 of the fp32 oracle -- outside the 1e-3 bar, which is stated
+    at T = 64.  Kept as a regression guard at 2e-3 with the arg-max still required identical."""
+    rel = _i3d_case(16)
+    assert rel <= I3D_SHORT_CLIP_TOL, rel
 
 
 def test_checkpoint_import_then_forward_matches_oracle(gpu, tmp_path):

@@ -392,9 +392,11 @@ def test_softmax_topk_nan_and_inf_rows(gpu):
     assert abs(prob[3, 0].item() - 1.0) < 1e-6 and prob[3, 1].item() == 0.0
 
 
-# the unit-test shape, then the BiLSTM head's own: hidden 512 over 64 steps, an odd batch that needs two passes
-# of four rows, and the full per-GPU batch of 16 clips
-@pytest.mark.parametrize("B,T,I,H", [(3, 9, 64, 32), (5, 64, 256, 512), (16, 64, 128, 512)])
+# the unit-test shape, then the BiLSTM head's own: hidden 512 over 64 steps with an odd batch, the full per-GPU batch
+# of 16 clips (one whole 16-row pass of the recurrence kernel), and batches that need a second and a third pass
+# (17 = 16 + 1, 33 = 16 + 16 + 1)
+@pytest.mark.parametrize("B,T,I,H", [(3, 9, 64, 32), (5, 64, 256, 512), (16, 64, 128, 512), (17, 12, 64, 128),
+                                     (33, 7, 32, 64)])
 def test_lstm_bidir_layer(gpu, B, T, I, H):
     """input-projection GEMM + fused recurrence against nn.LSTM (one bidirectional layer)"""
     from video_asl_recognition_amd import _lib as L
@@ -453,6 +455,22 @@ def test_layernorm_addrows_castpad(gpu):
     want = x + pe[torch.arange(rows) % 8]
     assert torch.equal(zf.cpu(), want) and torch.equal(zb.float().cpu(), _bf16(want))
     assert torch.equal(kb.float().cpu()[:, :42], _bf16(kp)) and kb[:, 42:].abs().sum() == 0
+
+
+def test_lstm_hidden_not_multiple_of_32(gpu):
+    """hidden % 8 == 0 but % 32 != 0 is a valid layer no kernel here covers: ASL_ENOTSUP, nothing launched;
+    hidden % 8 != 0 is an invalid request (ASL_EINVAL)."""
+    from video_asl_recognition_amd import _lib as L
+    for H, want in ((24, L.ASL_ENOTSUP), (12, L.ASL_EINVAL)):
+        B, T = 2, 3
+        gx = torch.zeros(B * T, 8 * H, device="cuda")
+        w_hh = torch.zeros(2, 4 * H, H, dtype=torch.bfloat16, device="cuda")
+        y = torch.full((B * T, 4 * H), 7.0, dtype=torch.bfloat16, device="cuda")
+        state = torch.empty(6 * B * H, device="cuda")
+        p = L.LstmParams(batch=B, t=T, hidden=H, ld_gx=8 * H, ld_y=4 * H, split_y=1, ysum_scale=1.0)
+        rc = L.lib.asl_lstm_bidir_layer(C.byref(p), _p(gx), _p(w_hh), _p(y), None, _p(state), None)
+        torch.cuda.synchronize()
+        assert rc == want and bool((y == 7.0).all())
 
 
 @pytest.mark.parametrize("B,T", [(2, 128), (3, 50)])

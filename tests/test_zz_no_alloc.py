@@ -2,7 +2,8 @@
 against asl_lstm_bidir_layer (state in caller scratch) through the C ABI.  The two share every kernel
 and the same launch order, so outputs must be bit-identical.  Two calls in a row, the second on a
 smaller input, so stale contents of the shared array from the first call would show; then the
-capacity limit."""
+capacity limit.  The static entry point is also checked on its own against torch.nn.LSTM (fp32, CPU),
+at a batch that needs three 16-row passes of the recurrence kernel."""
 import ctypes as C
 
 import pytest
@@ -38,8 +39,8 @@ def _run(L, B, T, H, gx, w_hh, static):
 
 def test_static_state_lstm_equals_caller_state_lstm(gpu):
     from video_asl_recognition_amd import _lib as L
-    # first call: the BiLSTM head's own shape (odd batch, two passes of four rows); second: smaller in
-    # every dimension, so it reuses a prefix of the array the first call left full of non-zero state
+    # first call: the BiLSTM head's own shape with an odd batch (one partly filled 16-row pass); second: smaller
+    # in every dimension, so it reuses a prefix of the array the first call left full of non-zero state
     for B, T, H, seed in ((5, 64, 512, 21), (2, 9, 32, 22)):
         gx, w_hh = _inputs(B, T, H, seed)
         y_ref, s_ref = _run(L, B, T, H, gx, w_hh, static=False)
@@ -66,3 +67,27 @@ def test_static_state_lstm_rejects_oversize(gpu):
     y_ref, _ = _run(L, B, T, H, gx, w_hh, static=False)
     y_st, _ = _run(L, B, T, H, gx, w_hh, static=True)
     assert torch.equal(y_st.view(torch.int16), y_ref.view(torch.int16))
+
+
+def test_static_state_lstm_matches_nn_lstm(gpu):
+    """The allocation-free entry point against torch.nn.LSTM itself (not only against its sibling): gx is the fp32
+    input projection computed on the CPU, so the kernel under test is the recurrence alone; B = 33 takes three
+    passes of 16 batch rows, the last one with a single live row."""
+    from video_asl_recognition_amd import _lib as L
+    B, T, I, H = 33, 10, 48, 64
+    torch.manual_seed(31)
+    lstm = torch.nn.LSTM(I, H, num_layers=1, bidirectional=True, batch_first=True)
+    with torch.no_grad():
+        for q in lstm.parameters():
+            q.copy_(q.to(torch.bfloat16).float())
+        x = torch.randn(B, T, I)
+        ref, _ = lstm(x)
+        sd = dict(lstm.named_parameters())
+        gx = torch.cat([x.reshape(B * T, I) @ sd["weight_ih_l0"].T + sd["bias_ih_l0"] + sd["bias_hh_l0"],
+                        x.reshape(B * T, I) @ sd["weight_ih_l0_reverse"].T + sd["bias_ih_l0_reverse"] + sd["bias_hh_l0_reverse"]], 1)
+        w_hh = torch.stack([sd["weight_hh_l0"], sd["weight_hh_l0_reverse"]], 0).to(torch.bfloat16).contiguous().cuda()
+    y, ysum = _run(L, B, T, H, gx.contiguous().cuda(), w_hh, static=True)
+    yy = y.float().view(B, T, 4 * H)
+    # hi + lo halves of h carry ~16 mantissa bits; tolerance as in the kernel's own test against nn.LSTM
+    torch.testing.assert_close(yy[..., :2 * H] + yy[..., 2 * H:], ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ysum, ref.mean(1), rtol=1e-4, atol=1e-5)

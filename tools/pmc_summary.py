@@ -51,7 +51,11 @@ def main(argv):
             print(f"{k},HBM_BYTES_corrected,{n},{per * 1024 * n:.6g},{per * 1024:.6g}")
     if json_out:
         stem = [k for k in hbm if "stem_pool_kernel" in k]
-        out = {"frames_per_chunk": fpc, "per_kernel": {}}
+        import os
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from video_asl_recognition_amd._lib import source_hash
+        # stamp: the kernel sources these counters were collected on (bench.py drops the figures when it differs)
+        out = {"frames_per_chunk": fpc, "source_hash": source_hash(), "per_kernel": {}}
         if stem:
             chunks = hbm[stem[0]][1]
             tot = sum(b * n for k, (b, n) in hbm.items() if "asl_detail" in k)

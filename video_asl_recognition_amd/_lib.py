@@ -134,6 +134,22 @@ for _name, (_args, _res) in _PROTOS.items():
     _fn.restype = _res
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, csrc/*.h, the
+    Makefile and the public header), in name order.  Counter summaries are stamped with it so a summary collected on
+    other kernels can be told apart from one collected on these."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files += [os.path.join(_HERE, "csrc", "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "asl_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def strerror(rc: int) -> str:
     return lib.asl_strerror(rc).decode()
 

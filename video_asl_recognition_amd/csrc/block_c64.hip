@@ -109,14 +109,19 @@ struct ConvSteps {
     __device__ static __forceinline__ void read(bf16x8 (&xf)[kRing], const unsigned (&ad)[9]) {
         xf[S % kRing] = lds_frag<(S & 3) * 512>(ad[S >> 2]);
     }
+    // the read issued right behind the MFMA of step S - kAhead: never into that MFMA's own fragment register
+    __device__ static __forceinline__ void read_after(bf16x8 (&xf)[kRing], const unsigned (&ad)[9]) {
+        xf[S % kRing] = lds_frag_after<(S & 3) * 512>(ad[S >> 2], xf[(S - kAhead) % kRing]);
+    }
     __device__ static __forceinline__ void run(f32x16 (&acc)[2], const bf16x8 (&w)[36], bf16x8 (&xf)[kRing], const unsigned (&ad)[9],
                                                TileEpilogue<kConv2>& epi) {
         constexpr int inflight = 35 - S < kAhead - 1 ? 35 - S : kAhead - 1;      // reads younger than step S's
 #if ASL_BLOCK_EXP != 2
-        mfma_step<kConv2, inflight, S < 2 ? 1 : S == 35 ? 2 : 0>(acc[S & 1], acc[(S & 1) ^ 1], w[S], xf[S % kRing]);
+        if constexpr (S == 35) mfma_last2<kConv2, inflight, S % 2>(acc, w[S], xf[S % kRing]);
+        else mfma_step<kConv2, inflight, S < 2 ? 1 : 0>(acc[S & 1], w[S], xf[S % kRing]);
 #endif
 #if ASL_BLOCK_EXP != 1
-        if constexpr (S + kAhead < 36) ConvSteps<kConv2, S + kAhead>::read(xf, ad);
+        if constexpr (S + kAhead < 36) ConvSteps<kConv2, S + kAhead>::read_after(xf, ad);
 #endif
         epi.template slice<S>();                          // a slice of the previous tile's epilogue ...
         __builtin_amdgcn_sched_barrier(0);                // ... pinned here: the scheduler would gather them in one place
@@ -363,7 +368,8 @@ extern "C" int asl_basic_block_c64_bf16(const asl_block_params* p, const void* x
     a.nstrips = p->n * a.strips_per_img;
     const int lds = (a.xpix + a.tpix) * 128 + 1024;      // images + BatchNorm constants
     static unsigned char lds_set[64];
-    if (const int e = ensure_dynamic_lds((const void*)block_c64_kernel, lds, lds_set)) return e;
+    // the attribute is set once per device, so to the largest size the search above can return, not to this request's
+    if (const int e = ensure_dynamic_lds((const void*)block_c64_kernel, kLds, lds_set)) return e;
     const int ncu = device_cus();
     const int grid = a.nstrips < ncu ? a.nstrips : ncu;
     hipLaunchKernelGGL(block_c64_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);

@@ -66,6 +66,13 @@ struct PairSteps {
     // At two waves per SIMD a wave has 128 accumulation registers and 128 ordinary ones: 32 of the bank's 36
     // fragments are addressed in the former, the last four in the latter.
     static constexpr int kBankA = 32;
+    // accumulation chains the 36 steps alternate over (1 = diagnostic build: one dependent chain, same results;
+    // block_mfma.h says what a one-chain loop must not do)
+#ifndef ASL_PAIR_CHAINS
+#define ASL_PAIR_CHAINS 2
+#endif
+    static constexpr int kChains = ASL_PAIR_CHAINS;
+    static_assert(kChains == 1 || kChains == 2, "one or two accumulation chains");
     __device__ static __forceinline__ void read(bf16x8 (&xf)[kRing], const unsigned (&ad)[9]) {
 #if ASL_PAIR_EXP == 1      // diagnostic build: K loop without its LDS reads (results wrong)
         asm volatile("" : "=v"(xf[S % kRing]) : "v"(ad[S >> 2]));
@@ -73,10 +80,20 @@ struct PairSteps {
         xf[S % kRing] = lds_frag<(S & 3) * 512>(ad[S >> 2]);
 #endif
     }
+    // the read issued right behind the MFMA of step S - kAhead: never into that MFMA's own fragment register
+    __device__ static __forceinline__ void read_after(bf16x8 (&xf)[kRing], const unsigned (&ad)[9]) {
+#if ASL_PAIR_EXP == 1
+        asm volatile("" : "=v"(xf[S % kRing]) : "v"(ad[S >> 2]));
+#else
+        xf[S % kRing] = lds_frag_after<(S & 3) * 512>(ad[S >> 2], xf[(S - kAhead) % kRing]);
+#endif
+    }
     __device__ static __forceinline__ void run(f32x16 (&acc)[2], const bf16x8 (&w)[36], bf16x8 (&xf)[kRing], const unsigned (&ad)[9]) {
         constexpr int inflight = 35 - S < kAhead - 1 ? 35 - S : kAhead - 1;      // reads younger than step S's
-        mfma_step<(S < kBankA), inflight, S < 2 ? 1 : S == 35 ? 2 : 0>(acc[S & 1], acc[(S & 1) ^ 1], w[S], xf[S % kRing]);
-        if constexpr (S + kAhead < 36) PairSteps<S + kAhead>::read(xf, ad);
+        if constexpr (S == 35 && kChains == 1) mfma_last1<(S < kBankA), inflight>(acc[0], w[S], xf[S % kRing]);
+        else if constexpr (S == 35) mfma_last2<(S < kBankA), inflight, S % 2>(acc, w[S], xf[S % kRing]);
+        else mfma_step<(S < kBankA), inflight, S < kChains ? 1 : 0>(acc[S % kChains], w[S], xf[S % kRing]);
+        if constexpr (S + kAhead < 36) PairSteps<S + kAhead>::read_after(xf, ad);
         if constexpr (S + 1 < 36) PairSteps<S + 1>::run(acc, w, xf, ad);
     }
 };
@@ -93,7 +110,8 @@ __device__ __forceinline__ f32x16 pair_tile(const bf16x8 (&w)[36], const unsigne
     static_assert(PairSteps<0>::kAhead >= 3 && PairSteps<0>::kAhead <= 6, "prefetch distance");
     f32x16 acc[2];
     PairSteps<0>::run(acc, w, xf, ad);
-    return acc[0] + acc[1];
+    if constexpr (PairSteps<0>::kChains == 1) return acc[0];
+    else return acc[0] + acc[1];
 }
 
 // BatchNorm, residual (conv2), ReLU on the rounded pair, masked: the lane's 16 channels as 8 packed dwords
@@ -412,7 +430,8 @@ int try_launch_block_c64_pair(const asl_block_params* p, const void* x, const vo
     a.dK = make_fastdiv((unsigned)a.K); a.dncs = make_fastdiv((unsigned)a.ncs);
     const int lds = 2 * (a.xpix + a.tpix) * 128 + kFixed;
     static unsigned char lds_set[64];
-    if (const int e = ensure_dynamic_lds((const void*)block_c64_pair_kernel, lds, lds_set)) return e;
+    // the attribute is set once per device, so to the largest size the search above can return, not to this request's
+    if (const int e = ensure_dynamic_lds((const void*)block_c64_pair_kernel, kLds, lds_set)) return e;
     const int ncu = device_cus();
     const int grid = a.nunits < ncu ? a.nunits : ncu;
     hipLaunchKernelGGL(block_c64_pair_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);

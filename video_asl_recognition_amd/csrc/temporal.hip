@@ -329,7 +329,8 @@ using namespace asl_detail;
 static int lstm_run(const asl_lstm_params* p, const float* gx, const void* w_hh, void* y_bf16, float* ysum,
                     float* state, hipStream_t s) {
     if (!p || !gx || !w_hh || !y_bf16 || !state) return ASL_EINVAL;
-    if (p->batch <= 0 || p->t <= 0 || p->hidden <= 0 || (p->hidden & 31)) return ASL_EINVAL;
+    if (p->batch <= 0 || p->t <= 0 || p->hidden <= 0 || (p->hidden & 7)) return ASL_EINVAL;
+    if (p->hidden & 31) return ASL_ENOTSUP;      // a valid layer, but the recurrence kernel steps K by 32
     if (p->ld_gx < 8 * p->hidden || p->ld_y < (p->split_y ? 4 : 2) * p->hidden) return ASL_EINVAL;
     if (((uintptr_t)w_hh & 15) || ((uintptr_t)state & 15)) return ASL_EINVAL;
     const long long n = 2LL * p->batch * p->hidden;           // elements of one [2][B][H] state array
