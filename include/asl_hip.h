@@ -93,7 +93,11 @@ typedef struct asl_gemm_params {
     int32_t w_rows;
     int64_t x_elems, y_elems, res_elems;
     int32_t variant;                 /* ASL_CONV_*                              */
-    int32_t reserved;                /* must be 0                               */
+    int32_t out_s2d;                 /* 0, or 1: 2-D output written as the space-to-depth cell tensor of its halo-1 image:
+                                        element offset of output pixel (h, w) = n*out.sn + ((h+1)>>1)*out.sh +
+                                        ((w+1)>>1)*out.sw + (((h+1)&1)*2 + ((w+1)&1))*out.sd + out.off0 (out.sd, unused by a
+                                        2-D output otherwise, is the plane stride); only the 3x3 large-tile kernel
+                                        (ASL_CONV_PP) writes it: other requests return ASL_ENOTSUP */
 } asl_gemm_params;
 
 int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, const void* w,
@@ -114,6 +118,10 @@ typedef struct asl_conv2d_params {
     int32_t relu;
     int32_t w_rows;
     int32_t variant;                 /* ASL_CONV_*; 0 = chosen by the library  */
+    int32_t out_s2d;                 /* 1: y is the space-to-depth cell tensor of the halo-1 output (see
+                                        asl_block_entry_s2_bf16); needs out_halo == 1, out_coff == 0, out_ctot == cout,
+                                        even oh and ow, and a kernel that can write it (3x3/s1/p1, cin >= 128,
+                                        cout % 128 == 0: ASL_ENOTSUP otherwise)            */
 } asl_conv2d_params;
 
 int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, const void* w,
@@ -137,11 +145,40 @@ typedef struct asl_block_params {
     int32_t in_halo, out_halo;
     int32_t w_rows;
     int32_t variant;
+    int32_t out_s2d;                 /* 1: y is the space-to-depth cell tensor of the halo-1 output (out_halo must be 1,
+                                        h and w even; paired kernel only: ASL_ENOTSUP with ASL_BLOCK_SOLO) */
 } asl_block_params;
 
 int asl_basic_block_c64_bf16(const asl_block_params* p, const void* x, const void* w1, const float* scale1,
                              const float* bias1, const void* w2, const float* scale2, const float* bias2,
                              void* y, asl_stream_t stream);
+
+/* Entry of a stride-2 residual block: nn.Conv2d(cin, cout, 3, stride 2, pad 1, bias=False) + BatchNorm2d(eval) [+ ReLU]
+ * -> y, and, from the same launch, the block's downsample nn.Conv2d(cin, cout, 1, stride 2, bias=False) +
+ * BatchNorm2d(eval) -> y_ds (torchvision BasicBlock.conv1/bn1/relu and BasicBlock.downsample of the first block of
+ * layers 2-4).  Both read x2, the space-to-depth cell tensor of the block's h x w x cin input (h, w even):
+ *     x2[n][(h+2)/2][(w+2)/2][4][cin] bf16, pixel (Y, X) of the halo-1 image in cell (Y>>1, X>>1), plane (Y&1)*2 + (X&1),
+ * zero where the halo is; asl_conv2d_nhwc_bf16 / asl_basic_block_c64_bf16 write it with out_s2d = 1.  On cells the
+ * stride-2 taps are stride-1 reads at constant offsets, so the input patch is staged once per tile and shared by all
+ * taps, and the downsample (the centre tap's pixels, plane 3) needs no second pass over the input.
+ *   w     bf16, MFMA-fragment order: [cout/128][cin/32][9 steps][2][4][64 lanes][8]; step order (ky,kx) = (0,0) (0,2)
+ *         (2,0) (2,2) (0,1) (2,1) (1,0) (1,2) (1,1); fragment (wc, j), lane (fq*16 + fr) holds input channels
+ *         32*group + 8*fq .. +7 of output channel 128*tile + 64*wc + 32*(j>>1) + 8*(fr>>2) + 4*(j&1) + (fr&3).
+ *         9*cin*cout elements (cout % 128 == 0: ASL_ENOTSUP otherwise; w_rows == cout).
+ *   w_ds  the same with one step per 32-channel group: [cout/128][cin/32][2][4][64][8]; NULL (with y_ds NULL): no downsample.
+ *   y     [n][h/2+2*out_halo][w/2+2*out_halo][cout];  y_ds [n][h/2+2*ds_halo][w/2+2*ds_halo][cout]; interiors only.
+ *   scale / bias fp32 [cout] or NULL (1 / 0).  relu applies to y only. */
+typedef struct asl_entry_params {
+    int32_t n, h, w, cin;
+    int32_t cout;
+    int32_t out_halo, ds_halo;
+    int32_t relu;
+    int32_t w_rows;
+} asl_entry_params;
+
+int asl_block_entry_s2_bf16(const asl_entry_params* p, const void* x2, const void* w, const float* scale,
+                            const float* bias, const void* w_ds, const float* scale_ds, const float* bias_ds,
+                            void* y, void* y_ds, asl_stream_t stream);
 
 /* First-layer convolution on packed RGB: nn.Conv2d(3, cout, (kh,kw), stride, pad) [+ BatchNorm2d
  * (eval)] [+ ReLU], e.g. the ResNet stem (7x7, stride 2, pad 3).  x is the packed clip tensor
@@ -348,6 +385,7 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
  *   ASL_OP_MEAN_T        NULL                    x, y                                    rows, t, c
  *   ASL_OP_HEAD          NULL                    x, w, b, y                              m, f, c
  *   ASL_OP_BASIC_BLOCK   asl_block_params*       x, w1, scale1, bias1, w2, scale2, bias2, y
+ *   ASL_OP_BLOCK_ENTRY   asl_entry_params*       x2, w, scale, bias, w_ds, scale_ds, bias_ds, y, y_ds
  *
  * Returns ASL_OK, or the first failing op's return code with its index in *failed (if failed != NULL); ops
  * before it have been issued, ops after it have not.  ASL_EINVAL for an unknown kind, a stream index outside
@@ -355,14 +393,14 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
 enum {
     ASL_OP_CONV2D = 1, ASL_OP_STEM_CONV = 2, ASL_OP_STEM_POOL = 3, ASL_OP_CONV3D = 4, ASL_OP_LINEAR = 5,
     ASL_OP_MAXPOOL3D = 6, ASL_OP_MAXPOOL = 7, ASL_OP_AVGPOOL = 8, ASL_OP_PACK_CLIPS = 9, ASL_OP_PREPROCESS = 10,
-    ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12, ASL_OP_BASIC_BLOCK = 13
+    ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12, ASL_OP_BASIC_BLOCK = 13, ASL_OP_BLOCK_ENTRY = 14
 };
 
 typedef struct asl_op {
     int32_t kind;
     int32_t stream;
     const void* params;
-    void* ptr[8];
+    void* ptr[10];
     int32_t i[8];
     float f[6];
 } asl_op;

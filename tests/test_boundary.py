@@ -34,8 +34,9 @@ def test_version_and_strerror():
 
 def test_struct_sizes_match_header_layout():
     from video_asl_recognition_amd import _lib as L
-    assert C.sizeof(L.Geom) == 24 and C.sizeof(L.BlockParams) == 8 * 4
-    assert C.sizeof(L.Conv2dParams) == 19 * 4
+    assert C.sizeof(L.Geom) == 24 and C.sizeof(L.BlockParams) == 9 * 4
+    assert C.sizeof(L.Conv2dParams) == 20 * 4 and C.sizeof(L.EntryParams) == 9 * 4
+    assert C.sizeof(L.Op) == 8 + 8 + 10 * 8 + 8 * 4 + 6 * 4
     assert C.sizeof(L.StemParams) == 12 * 4
     assert C.sizeof(L.Conv3dParams) == 21 * 4
     assert C.sizeof(L.LinearParams) == 10 * 4
@@ -66,6 +67,13 @@ def test_bad_geometry_is_rejected_without_launch():
     assert L.lib.asl_pack_clips(fake, 1, 1, 31, 3, fake, None) == L.ASL_EINVAL                                # odd size
     assert L.lib.asl_softmax_topk(fake, 1, 10, 17, fake, fake, None) == L.ASL_EINVAL                          # k > 16
     assert L.lib.asl_avgpool_nhwc(fake, 1, 7, 7, 24 * 8, 1, fake, None, 0, 0, None) == L.ASL_EINVAL              # c/8 not pow2
+    ep = L.EntryParams(n=1, h=7, w=8, cin=64, cout=128, out_halo=1, ds_halo=0, relu=1, w_rows=128)
+    assert L.lib.asl_block_entry_s2_bf16(C.byref(ep), fake, fake, None, None, None, None, None, fake, None, None) == L.ASL_EINVAL  # odd h
+    p.out_s2d = 1                                                                                            # cells need an even grid ...
+    p.h = 7
+    assert L.lib.asl_conv2d_nhwc_bf16(C.byref(p), fake, fake, None, None, None, fake, None) == L.ASL_EINVAL
+    p.h, p.out_halo = 8, 0                                                                                   # ... and halo 1
+    assert L.lib.asl_conv2d_nhwc_bf16(C.byref(p), fake, fake, None, None, None, fake, None) == L.ASL_EINVAL
     with pytest.raises(RuntimeError, match="invalid argument"):
         L.check(L.ASL_EINVAL, "probe")
 

@@ -54,6 +54,21 @@ def test_resnet18_forward_matches_oracle(gpu, B, T, chunk):
         assert rel_l2(y, torch.from_numpy(g["logits"])) <= REL_TOL
 
 
+def test_resnet18_cell_entry_path_matches_oracle(gpu):
+    """the opt-in one-launch stride-2 block entries (cell tensors written by the previous block's kernel): same bar as
+    the default path, and within bf16 rounding of it"""
+    om, m = _model("resnet18_mean", frames_per_chunk=8, s2d_entry=True)
+    _, m0 = _model("resnet18_mean", frames_per_chunk=8, s2d_entry=False)
+    clips = O.make_clips(2, 8, 224, 0)
+    y, y0 = m(clips.cuda()).cpu(), m0(clips.cuda()).cpu()
+    with torch.no_grad():
+        ref = om(clips)
+    kinds = [int(r["op"].kind) for r in m._plan[0]["ops"]]
+    assert kinds.count(14) == 3, "three stride-2 entries expected on the one-launch path"      # ASL_OP_BLOCK_ENTRY
+    assert rel_l2(y, ref) <= REL_TOL and torch.equal(y.argmax(1), ref.argmax(1))
+    assert rel_l2(y, y0) <= 3e-4
+
+
 def test_resnet18_bf16_input_equals_fp32_input(gpu):
     """inputs are bf16-representable, so handing them over as bf16 must change nothing"""
     _, m = _model("resnet18_mean")

@@ -151,6 +151,127 @@ def _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu, variant=0):
     assert torch.equal(y1, yd), "two launches on the same input differ"
 
 
+# Stride-2 block entry on the cell tensor: the three ResNet shapes (tiles straddling rows and images, several channel
+# tiles, a short last tile), one and ten channel groups, rows wider than a fragment, a single mostly idle tile, no
+# downsample
+ENTRY_CASES = [
+    # n, h, w, cin, cout, with_ds, relu
+    (5, 56, 56, 64, 128, True, True),
+    (11, 28, 28, 128, 256, True, True),
+    (37, 14, 14, 256, 512, True, True),
+    (3, 10, 12, 32, 128, True, False),
+    (2, 36, 40, 320, 128, True, True),
+    (1, 4, 6, 64, 256, False, True),
+    (70, 14, 14, 128, 128, True, True),
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,with_ds,relu", ENTRY_CASES)
+def test_block_entry_s2(gpu, n, h, w, cin, cout, with_ds, relu):
+    """asl_block_entry_s2_bf16 against F.conv2d(3x3, stride 2, pad 1) + BN (+ReLU) and F.conv2d(1x1, stride 2) + BN"""
+    from video_asl_recognition_amd import _lib as L
+    from video_asl_recognition_amd.packing import pack_entry_conv, pack_entry_ds, to_cells
+    g = torch.Generator().manual_seed(h * 17 + cin)
+    x = _bf16(torch.randn(n, cin, h, w, generator=g))
+    w3 = _bf16(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+    w1 = _bf16(torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5)
+    sc, sd = torch.empty(cout).uniform_(0.5, 1.5, generator=g), torch.empty(cout).uniform_(0.5, 1.5, generator=g)
+    bc, bd = torch.empty(cout).normal_(0, 0.1, generator=g), torch.empty(cout).normal_(0, 0.1, generator=g)
+    v = lambda t: t.view(1, -1, 1, 1)
+    ref = F.conv2d(x, w3, None, 2, 1) * v(sc) + v(bc)
+    if relu:
+        ref = F.relu(ref)
+    ref_ds = F.conv2d(x, w1, None, 2, 0) * v(sd) + v(bd)
+    pc = pack_entry_conv(w3, "cuda", scale=sc.cuda(), bias=bc.cuda())
+    pd = pack_entry_ds(w1, "cuda", scale=sd.cuda(), bias=bd.cuda())
+    x2 = to_cells(_halo(x, 1))
+    oh, ow = h // 2, w // 2
+    yd = torch.full((n, oh + 2, ow + 2, cout), 5.0, dtype=torch.bfloat16, device="cuda")
+    yds = torch.full((n, oh, ow, cout), 5.0, dtype=torch.bfloat16, device="cuda")
+    p = L.EntryParams(n=n, h=h, w=w, cin=cin, cout=cout, out_halo=1, ds_halo=0, relu=int(relu), w_rows=cout)
+    args = (C.byref(p), _p(x2), _p(pc.w), _p(pc.scale), _p(pc.bias)) + \
+        ((_p(pd.w), _p(pd.scale), _p(pd.bias), _p(yd), _p(yds)) if with_ds else (None, None, None, _p(yd), None)) + (None,)
+    L.check(L.lib.asl_block_entry_s2_bf16(*args), "entry")
+    torch.cuda.synchronize()
+    assert bool((yd[:, 0] == 5.0).all()) and bool((yd[:, :, -1] == 5.0).all()), "halo was written"
+    _assert_bf16_close(_unhalo(yd, 1), ref)
+    if with_ds:
+        _assert_bf16_close(_unhalo(yds, 0), ref_ds)
+    else:
+        assert bool((yds == 5.0).all())
+    y1, d1 = yd.clone(), yds.clone()
+    L.check(L.lib.asl_block_entry_s2_bf16(*args), "entry")
+    torch.cuda.synchronize()
+    assert torch.equal(y1, yd) and torch.equal(d1, yds), "two launches on the same input differ"
+
+
+def test_block_entry_s2_rejects(gpu):
+    from video_asl_recognition_amd import _lib as L
+    x2 = torch.zeros(1, 4, 4, 4, 32, dtype=torch.bfloat16, device="cuda")
+    wz = torch.zeros(9 * 32 * 128, dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(1, 5, 5, 128, dtype=torch.bfloat16, device="cuda")
+    ok = dict(n=1, h=6, w=6, cin=32, cout=128, out_halo=1, ds_halo=0, relu=1, w_rows=128)
+    for bad, want in ((dict(h=5), L.ASL_EINVAL), (dict(cin=48), L.ASL_EINVAL), (dict(cout=64, w_rows=64), L.ASL_ENOTSUP)):
+        p = L.EntryParams(**{**ok, **bad})
+        assert L.lib.asl_block_entry_s2_bf16(C.byref(p), _p(x2), _p(wz), None, None, None, None, None, _p(y), None, None) == want
+    # a downsample weight without its output (or the reverse) is a malformed request
+    p = L.EntryParams(**ok)
+    assert L.lib.asl_block_entry_s2_bf16(C.byref(p), _p(x2), _p(wz), None, None, _p(wz), None, None, _p(y), None, None) == L.ASL_EINVAL
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,res", [(9, 28, 28, 128, 128, True), (40, 14, 14, 256, 256, True), (3, 12, 18, 320, 128, False)])
+def test_conv3x3_cell_output(gpu, n, h, w, cin, cout, res):
+    """out_s2d = 1: the 8-wave 3x3 kernel writes the cell tensor a stride-2 block entry reads; bit-identical to its plain
+    halo-1 output rearranged, halo cells untouched"""
+    from video_asl_recognition_amd import _lib as L
+    from video_asl_recognition_amd.packing import pack_conv, from_cells
+    g = torch.Generator().manual_seed(h + cin)
+    x = _bf16(torch.randn(n, cin, h, w, generator=g))
+    wt = _bf16(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+    pc = pack_conv(wt, "cuda", scale=torch.empty(cout).uniform_(0.5, 1.5, generator=g).cuda(),
+                   bias=torch.empty(cout).normal_(0, 0.1, generator=g).cuda())
+    xd = _halo(x, 1)
+    rd = _halo(_bf16(torch.randn(n, cout, h, w, generator=g)), 1) if res else None
+    y_plain = torch.zeros(n, h + 2, w + 2, cout, dtype=torch.bfloat16, device="cuda")
+    y_cells = torch.zeros(n, (h + 2) // 2, (w + 2) // 2, 4, cout, dtype=torch.bfloat16, device="cuda")
+    kw = dict(n=n, h=h, w=w, cin=cin, in_halo=1, cout=cout, kh=3, kw=3, stride=1, pad=1, out_halo=1, out_ctot=cout, out_coff=0,
+              res_halo=1, res_ctot=cout, res_coff=0, relu=1, w_rows=pc.w_rows, variant=L.CONV_PP)
+    p0, p1 = L.Conv2dParams(**kw), L.Conv2dParams(out_s2d=1, **kw)
+    L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(p0), _p(xd), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(rd), _p(y_plain), None))
+    L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(p1), _p(xd), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(rd), _p(y_cells), None))
+    torch.cuda.synchronize()
+    assert float(y_plain.float().abs().sum()) > 0
+    assert torch.equal(from_cells(y_cells), y_plain)
+    # kernels that cannot write cells refuse the request instead of writing the plain layout into it
+    p2 = L.Conv2dParams(out_s2d=1, **{**kw, "variant": L.CONV_GATHER})
+    assert L.lib.asl_conv2d_nhwc_bf16(C.byref(p2), _p(xd), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(rd), _p(y_cells), None) == L.ASL_ENOTSUP
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 56, 56), (2, 30, 56), (4, 18, 100)])
+def test_fused_basic_block_cell_output(gpu, n, h, w):
+    """out_s2d = 1 on the paired fused BasicBlock: bit-identical to its plain output rearranged"""
+    from video_asl_recognition_amd import _lib as L
+    from video_asl_recognition_amd.packing import pack_conv, from_cells
+    g = torch.Generator().manual_seed(h * 3 + w)
+    x = _bf16(torch.randn(n, 64, h, w, generator=g))
+    mk = lambda: pack_conv(_bf16(torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5), "cuda",
+                           scale=torch.empty(64).uniform_(0.3, 1.2, generator=g).cuda(), bias=torch.empty(64).normal_(0, 0.1, generator=g).cuda())
+    p1, p2 = mk(), mk()
+    xd = _halo(x, 1)
+    y_plain = torch.zeros(n, h + 2, w + 2, 64, dtype=torch.bfloat16, device="cuda")
+    y_cells = torch.zeros(n, (h + 2) // 2, (w + 2) // 2, 4, 64, dtype=torch.bfloat16, device="cuda")
+    for out_s2d, y in ((0, y_plain), (1, y_cells)):
+        p = L.BlockParams(n=n, h=h, w=w, channels=64, in_halo=1, out_halo=1, w_rows=p1.w_rows, variant=2, out_s2d=out_s2d)
+        L.check(L.lib.asl_basic_block_c64_bf16(C.byref(p), _p(xd), _p(p1.w), _p(p1.scale), _p(p1.bias), _p(p2.w), _p(p2.scale),
+                                               _p(p2.bias), _p(y), None), "block")
+    torch.cuda.synchronize()
+    assert float(y_plain.float().abs().sum()) > 0
+    assert torch.equal(from_cells(y_cells), y_plain)
+    p = L.BlockParams(n=n, h=h, w=w, channels=64, in_halo=1, out_halo=1, w_rows=p1.w_rows, variant=1, out_s2d=1)
+    assert L.lib.asl_basic_block_c64_bf16(C.byref(p), _p(xd), _p(p1.w), _p(p1.scale), _p(p1.bias), _p(p2.w), _p(p2.scale),
+                                          _p(p2.bias), _p(y_cells), None) == L.ASL_ENOTSUP
+
+
 # fused 64-channel BasicBlock: strips of 7 rows on 56x56; a last strip shorter than the others; rows wider and
 # narrower than a 32-pixel tile; more strips than CUs (several per persistent workgroup); an image smaller than
 # one strip; output halo 0 and 2

@@ -28,17 +28,21 @@ class GemmParams(C.Structure):
                 ("in_", Geom), ("out", Geom), ("res", Geom),
                 ("relu", C.c_int32), ("out_f32", C.c_int32), ("res_f32", C.c_int32), ("w_rows", C.c_int32),
                 ("x_elems", C.c_int64), ("y_elems", C.c_int64), ("res_elems", C.c_int64),
-                ("variant", C.c_int32), ("reserved", C.c_int32)]
+                ("variant", C.c_int32), ("out_s2d", C.c_int32)]
 
 
 class Conv2dParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "h", "w", "cin", "in_halo", "cout", "kh", "kw", "stride", "pad",
-        "out_halo", "out_ctot", "out_coff", "res_halo", "res_ctot", "res_coff", "relu", "w_rows", "variant")]
+        "out_halo", "out_ctot", "out_coff", "res_halo", "res_ctot", "res_coff", "relu", "w_rows", "variant", "out_s2d")]
 
 
 class BlockParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "channels", "in_halo", "out_halo", "w_rows", "variant")]
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "channels", "in_halo", "out_halo", "w_rows", "variant", "out_s2d")]
+
+
+class EntryParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "cin", "cout", "out_halo", "ds_halo", "relu", "w_rows")]
 
 
 class StemParams(C.Structure):
@@ -72,12 +76,12 @@ class LstmParams(C.Structure):
 
 class Op(C.Structure):
     """asl_op: one launch as data, for asl_run_ops"""
-    _fields_ = [("kind", C.c_int32), ("stream", C.c_int32), ("params", C.c_void_p), ("ptr", C.c_void_p * 8),
+    _fields_ = [("kind", C.c_int32), ("stream", C.c_int32), ("params", C.c_void_p), ("ptr", C.c_void_p * 10),
                 ("i", C.c_int32 * 8), ("f", C.c_float * 6)]
 
 
 (OP_CONV2D, OP_STEM_CONV, OP_STEM_POOL, OP_CONV3D, OP_LINEAR, OP_MAXPOOL3D, OP_MAXPOOL, OP_AVGPOOL, OP_PACK_CLIPS,
- OP_PREPROCESS, OP_MEAN_T, OP_HEAD, OP_BASIC_BLOCK) = range(1, 14)
+ OP_PREPROCESS, OP_MEAN_T, OP_HEAD, OP_BASIC_BLOCK, OP_BLOCK_ENTRY) = range(1, 15)
 
 
 class AttnParams(C.Structure):
@@ -104,6 +108,7 @@ _PROTOS = {
     "asl_gather_gemm_bf16": ([C.POINTER(GemmParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_conv2d_nhwc_bf16": ([C.POINTER(Conv2dParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_basic_block_c64_bf16": ([C.POINTER(BlockParams)] + [_P] * 9, C.c_int),
+    "asl_block_entry_s2_bf16": ([C.POINTER(EntryParams)] + [_P] * 10, C.c_int),
     "asl_stem_conv_bf16": ([C.POINTER(StemParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_stem_pool_bf16": ([C.POINTER(StemPoolParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_conv3d_ndhwc_bf16": ([C.POINTER(Conv3dParams), _P, _P, _P, _P, _P, _P], C.c_int),

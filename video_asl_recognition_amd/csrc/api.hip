@@ -5,7 +5,7 @@
 
 #include "asl_hip.h"
 
-extern "C" int asl_version(void) { return 101; }
+extern "C" int asl_version(void) { return 102; }
 
 extern "C" const char* asl_strerror(int rc) {
     switch (rc) {
@@ -39,6 +39,15 @@ extern "C" int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, c
     g.out.sh = owp * p->out_ctot; g.out.sw = p->out_ctot;
     g.out.off0 = (p->out_halo * owp + p->out_halo) * p->out_ctot + p->out_coff;
     g.y_elems = (int64_t)p->n * g.out.sn;
+    if (p->out_s2d) {
+        // cells of the halo-1 output image: [n][ohp/2][owp/2][4][cout]
+        if (p->out_s2d != 1 || p->out_halo != 1 || p->out_coff != 0 || p->out_ctot != p->cout || (oh & 1) || (ow & 1))
+            return ASL_EINVAL;
+        g.out.sn = (int64_t)(ohp / 2) * (owp / 2) * 4 * p->cout;
+        g.out.sh = (owp / 2) * 4 * p->cout; g.out.sw = 4 * p->cout; g.out.sd = p->cout; g.out.off0 = 0;
+        g.y_elems = (int64_t)p->n * g.out.sn;
+        g.out_s2d = 1;
+    }
     if (res) {
         if (p->res_halo < 0 || p->res_coff < 0 || p->res_coff + p->cout > p->res_ctot) return ASL_EINVAL;
         const int rwp = ow + 2 * p->res_halo, rhp = oh + 2 * p->res_halo;
@@ -190,6 +199,11 @@ extern "C" int asl_run_ops(const asl_op* ops, int count, const asl_stream_t* str
                     rc = asl_basic_block_c64_bf16((const asl_block_params*)o.params, p[0], p[1], (const float*)p[2],
                                                   (const float*)p[3], p[4], (const float*)p[5], (const float*)p[6],
                                                   p[7], s);
+                    break;
+                case ASL_OP_BLOCK_ENTRY:
+                    rc = asl_block_entry_s2_bf16((const asl_entry_params*)o.params, p[0], p[1], (const float*)p[2],
+                                                 (const float*)p[3], p[4], (const float*)p[5], (const float*)p[6],
+                                                 p[7], p[8], s);
                     break;
                 default:
                     rc = ASL_EINVAL;

@@ -338,11 +338,13 @@ extern "C" int asl_basic_block_c64_bf16(const asl_block_params* p, const void* x
         ((uintptr_t)scale1 & 15) || ((uintptr_t)bias1 & 15) || ((uintptr_t)scale2 & 15) || ((uintptr_t)bias2 & 15))
         return ASL_EINVAL;
     if (x == y) return ASL_EINVAL;                          // strips re-read rows that other strips have already replaced
+    if (p->out_s2d && (p->out_s2d != 1 || p->out_halo != 1 || (p->h & 1) || (p->w & 1))) return ASL_EINVAL;
     if (p->variant != ASL_BLOCK_SOLO) {
         const int e = try_launch_block_c64_pair(p, x, w1, scale1, bias1, w2, scale2, bias2, y, (hipStream_t)stream);
         if (e != -1) return e;
         if (p->variant == ASL_BLOCK_PAIRED) return ASL_ENOTSUP;
     }
+    if (p->out_s2d) return ASL_ENOTSUP;                     // only the paired kernel writes the cell layout
     BlockArgs a;
     a.x = (const char*)x; a.w1 = (const char*)w1; a.w2 = (const char*)w2; a.y = (char*)y;
     a.s1 = scale1; a.b1 = bias1; a.s2 = scale2; a.b2 = bias2;

@@ -54,6 +54,7 @@ struct PairArgs {
     long long x_bytes;
     long long out_sn;
     int out_sh;
+    int out_s2d;                   // 1: y is the cell tensor of the halo-1 output (out_sn / out_sh are per image / cell row)
     FastDiv dTW, dCW, dXW, dK, dncs;
 };
 
@@ -377,8 +378,11 @@ __global__ __launch_bounds__(512, 1) void block_c64_pair_kernel(const PairArgs a
                     continue;
 #endif
                     pair_finish<true>(acc, bnl, res, true, out);
-                    char* const dst = a.y + 2 * ((long long)img * a.out_sn + (long long)((ok ? yo : 0) + a.out_halo) * a.out_sh +
-                                                 (long long)((ok ? xo : 0) + a.out_halo) * 64 + chl);
+                    const int yh = (ok ? yo : 0) + a.out_halo, xh = (ok ? xo : 0) + a.out_halo;      // halo'd output pixel
+                    char* const dst = a.out_s2d
+                        ? a.y + 2 * ((long long)img * a.out_sn + (long long)(yh >> 1) * a.out_sh + (long long)(xh >> 1) * 256 +
+                                     ((yh & 1) * 2 + (xh & 1)) * 64 + chl)
+                        : a.y + 2 * ((long long)img * a.out_sn + (long long)yh * a.out_sh + (long long)xh * 64 + chl);
                     if (ok) {
                         *(i32x4*)dst = i32x4{(int)out[0], (int)out[1], (int)out[2], (int)out[3]};
                         *(i32x4*)(dst + 16) = i32x4{(int)out[4], (int)out[5], (int)out[6], (int)out[7]};
@@ -407,6 +411,8 @@ int try_launch_block_c64_pair(const asl_block_params* p, const void* x, const vo
     if ((long long)a.Hp * a.Wp >= (1LL << 23)) return -1;  // 32-bit byte offsets within one image
     const int owp = p->w + 2 * p->out_halo, ohp = p->h + 2 * p->out_halo;
     a.out_sn = (long long)ohp * owp * 64; a.out_sh = owp * 64;
+    a.out_s2d = p->out_s2d ? 1 : 0;
+    if (a.out_s2d) { a.out_sn = (long long)(ohp / 2) * (owp / 2) * 256; a.out_sh = (owp / 2) * 256; }
     // the fewest column strips whose images leave room for steps of at least min(8, h) rows
     constexpr int kLds = 160 * 1024, kFixed = 2048 + 1024;
     const int want = p->h < 8 ? p->h : 8;

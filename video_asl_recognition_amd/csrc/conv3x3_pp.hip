@@ -285,7 +285,10 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
             m = ok ? m : mend - 1;
             const int n = (int)fdiv(m, a.dOHW), r1 = m - n * HW;
             const int y = (int)fdiv(r1, a.dOW), x = r1 - y * a.W;
-            const long long o = (long long)n * a.out_sn + (long long)y * a.out_sh + (long long)x * a.out_sw + a.out_off0 + ch0;
+            long long o = (long long)n * a.out_sn + (long long)y * a.out_sh + (long long)x * a.out_sw + a.out_off0 + ch0;
+            if (a.out_s2d)          // cell layout for a stride-2 consumer: cell ((y+1)>>1, (x+1)>>1), plane by the parities
+                o = (long long)n * a.out_sn + (long long)((y + 1) >> 1) * a.out_sh + (long long)((x + 1) >> 1) * a.out_sw +
+                    (((y + 1) & 1) * 2 + ((x + 1) & 1)) * a.out_s2d + a.out_off0 + ch0;
             const long long r = (long long)n * a.res_sn + (long long)y * a.res_sh + (long long)x * a.res_sw + a.res_off0 + ch0;
             oe[i] = ok ? (unsigned)(2 * o) : kOobOff;
             re[i] = ok ? (unsigned)(2 * r) : kOobOff;

@@ -32,6 +32,8 @@ struct PatchArgs {
     unsigned long long* stamps;   // diagnostic builds only (ASL_STAMPS): 5 s_memtime stamps per workgroup
     int stagger_ticks;     // one-time start delay (100 MHz ticks) of the second resident workgroup set
     int variant;           // ASL_CONV_* requested by the caller (0: the library chooses)
+    int out_s2d;           // 0, or the plane stride (elements) of a space-to-depth output: pixel (y, x) goes to cell
+                           // ((y+1)>>1, (x+1)>>1) (strides out_sh, out_sw), plane ((y+1)&1)*2 + ((x+1)&1); conv3x3_pp only
 };
 
 // compute units of the current device (cached per device; 256 when the query fails)

@@ -20,7 +20,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib as L
-from .packing import PackedConv, bn_scale_bias, pack_conv, pack_linear, pack_stem
+from .packing import PackedConv, bn_scale_bias, pack_conv, pack_entry_conv, pack_entry_ds, pack_linear, pack_stem
 from .spec import RESNET_LAYERS, SPECS, ModelSpec, param_shapes, resnet_blocks
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -32,15 +32,20 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class Act:
-    """Channels-last bf16 activation buffer with a zero halo: [n][h+2*halo][w+2*halo][c]."""
+    """Channels-last bf16 activation buffer with a zero halo: [n][h+2*halo][w+2*halo][c]; with cells=True the same
+    halo-1 image as space-to-depth cells [n][(h+2)/2][(w+2)/2][4][c] (the input layout of a stride-2 block entry)."""
 
-    def __init__(self, n, h, w, c, halo, device):
-        self.n, self.h, self.w, self.c, self.halo = n, h, w, c, halo
-        self.t = torch.zeros(n, h + 2 * halo, w + 2 * halo, c, dtype=torch.bfloat16, device=device)
+    def __init__(self, n, h, w, c, halo, device, cells=False):
+        self.n, self.h, self.w, self.c, self.halo, self.cells = n, h, w, c, halo, cells
+        if cells:
+            assert halo == 1 and h % 2 == 0 and w % 2 == 0
+            self.t = torch.zeros(n, (h + 2) // 2, (w + 2) // 2, 4, c, dtype=torch.bfloat16, device=device)
+        else:
+            self.t = torch.zeros(n, h + 2 * halo, w + 2 * halo, c, dtype=torch.bfloat16, device=device)
 
     @property
     def key(self):
-        return (self.h, self.w, self.c, self.halo)
+        return (self.h, self.w, self.c, self.halo, self.cells)
 
     def interior(self, n=None):
         hl = self.halo
@@ -54,11 +59,11 @@ class _BufPool:
         self.free: Dict[tuple, List[Act]] = {}
         self.all: List[Act] = []
 
-    def get(self, h, w, c, halo=1) -> Act:
-        lst = self.free.get((h, w, c, halo))
+    def get(self, h, w, c, halo=1, cells=False) -> Act:
+        lst = self.free.get((h, w, c, halo, cells))
         if lst:
             return lst.pop()
-        a = Act(self.n, h, w, c, halo, self.device)
+        a = Act(self.n, h, w, c, halo, self.device, cells)
         self.all.append(a)
         return a
 
@@ -71,7 +76,7 @@ class _BufPool:
 
 class AslClipModel:
     def __init__(self, spec, device: str = "cuda", frames_per_chunk: int = 256, seed: Optional[int] = None,
-                 streams: int = 2):
+                 streams: int = 2, s2d_entry: Optional[bool] = None):
         self.spec: ModelSpec = SPECS[spec] if isinstance(spec, str) else spec
         if not torch.cuda.is_available():
             raise RuntimeError("AslClipModel needs an MI355X (no GPU visible); there is no CPU path")
@@ -87,6 +92,10 @@ class AslClipModel:
         # one kernel per 64-channel BasicBlock (asl_basic_block_c64_bf16) instead of two conv launches: half the HBM
         # traffic of layer 1; ASL_FUSE_BLOCKS=0 keeps the two-launch form
         self.fuse_blocks = os.environ.get("ASL_FUSE_BLOCKS", "1") == "1"
+        # stride-2 BasicBlocks: conv1 and the downsample from one launch over a cell copy of the block's input that the
+        # previous block's last kernel writes (asl_block_entry_s2_bf16).  Opt-in (argument, or ASL_S2D_ENTRY=1): measured
+        # slower than the two gather-GEMM launches it replaces (254 / 188 / 145 us against 190 / 122 / 105 at 640 frames)
+        self.s2d_entry = (os.environ.get("ASL_S2D_ENTRY", "0") == "1") if s2d_entry is None else bool(s2d_entry)
         self._w: Dict[str, PackedConv] = {}
         self._fc_w = self._fc_b = None
         self._temporal = None
@@ -122,6 +131,11 @@ class AslClipModel:
                 if ds:
                     s, b = bn_scale_bias(sd, f"{prefix}.downsample.1", 1e-5, dev)
                     w[f"{prefix}.ds"] = pack_conv(sd[f"{prefix}.downsample.0.weight"], dev, scale=s, bias=b)
+                    if nconv == 2 and stride == 2 and cin % 32 == 0 and planes % 128 == 0:
+                        # the same two weight sets in MFMA-fragment order for the one-launch block entry
+                        c1 = w[f"{prefix}.conv1"]
+                        w[f"{prefix}.entry"] = pack_entry_conv(sd[f"{prefix}.conv1.weight"], dev, c1.scale, c1.bias)
+                        w[f"{prefix}.entry_ds"] = pack_entry_ds(sd[f"{prefix}.downsample.0.weight"], dev, s, b)
         elif spec.backbone == "i3d":
             from .i3d import pack_i3d_weights
             w = pack_i3d_weights(spec, sd, dev)
@@ -160,7 +174,7 @@ class AslClipModel:
             p = L.Conv2dParams(n=0, h=x.h, w=x.w, cin=x.c, in_halo=x.halo, cout=pc.cout, kh=kh, kw=kw,
                                stride=stride, pad=pad, out_halo=y.halo, out_ctot=y.c, out_coff=0,
                                res_halo=res.halo if res else 0, res_ctot=res.c if res else 0, res_coff=0,
-                               relu=int(relu), w_rows=pc.w_rows, variant=self.conv_variant)
+                               relu=int(relu), w_rows=pc.w_rows, variant=self.conv_variant, out_s2d=int(y.cells))
             add(L.OP_CONV2D, p, (x.t, pc.w, pc.scale, pc.bias, res.t if res else None, y.t), conv=True, keep=(x, y, res, pc))
 
         def stem_op(pc: PackedConv, x0: torch.Tensor, in_halo, y: Act, stride, pad, relu):
@@ -190,24 +204,42 @@ class AslClipModel:
                 sp = L.StemPoolParams(n=0, h=S, w=S, cout=pc.cout, out_halo=x.halo, w_rows=pc.w_rows)
                 add(L.OP_STEM_POOL, sp, (x0, pc.w, pc.scale, pc.bias, x.t), conv=True, keep=(x, pc))
             basic = RESNET_LAYERS[spec.backbone][0] == "basic"
-            for prefix, cin, planes, stride, ds in resnet_blocks(spec.backbone):
+            blocks = list(resnet_blocks(spec.backbone))
+            cells_ok = basic and self.s2d_entry and self.conv_variant in (0, L.CONV_PP)
+            for bi, (prefix, cin, planes, stride, ds) in enumerate(blocks):
                 oh, ow = x.h // stride, x.w // stride
                 w = self._w
-                if basic and self.fuse_blocks and not ds and stride == 1 and cin == planes == 64:
+                # the next block is a stride-2 entry that can take its input as cells, and this block's last kernel can
+                # write them (the paired fused block; the 8-wave 3x3 kernel: 128 channels and up, whole 128-channel tiles)
+                nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+                fused = basic and self.fuse_blocks and not ds and stride == 1 and cin == planes == 64
+                y_cells = bool(cells_ok and nxt and (nxt[0] + ".entry") in w and oh % 2 == 0 and ow % 2 == 0 and
+                               (fused or (planes >= 128 and planes % 128 == 0)))
+                if fused:
                     # both convs of the block in one kernel: the intermediate activation stays on the chip
                     c1, c2 = w[prefix + ".conv1"], w[prefix + ".conv2"]
-                    y = pool.get(oh, ow, planes)
-                    bp = L.BlockParams(n=0, h=x.h, w=x.w, channels=64, in_halo=x.halo, out_halo=y.halo, w_rows=c1.w_rows)
+                    y = pool.get(oh, ow, planes, cells=y_cells)
+                    bp = L.BlockParams(n=0, h=x.h, w=x.w, channels=64, in_halo=x.halo, out_halo=y.halo, w_rows=c1.w_rows,
+                                       variant=2 if y_cells else 0, out_s2d=int(y_cells))
                     add(L.OP_BASIC_BLOCK, bp, (x.t, c1.w, c1.scale, c1.bias, c2.w, c2.scale, c2.bias, y.t), conv=True,
                         keep=(x, y, c1, c2))
                 elif basic:
                     t = pool.get(oh, ow, planes)
-                    conv_op(w[prefix + ".conv1"], x, t, stride, 1, True)
                     idt = x
-                    if ds:
+                    if x.cells:
+                        # conv1 (3x3 / stride 2) and the downsample (1x1 / stride 2) from one launch over the cells
+                        e1, e2 = w[prefix + ".entry"], w[prefix + ".entry_ds"]
                         idt = pool.get(oh, ow, planes)
-                        conv_op(w[prefix + ".ds"], x, idt, stride, 0, False)
-                    y = pool.get(oh, ow, planes)
+                        ep = L.EntryParams(n=0, h=x.h, w=x.w, cin=x.c, cout=planes, out_halo=t.halo, ds_halo=idt.halo, relu=1,
+                                           w_rows=planes)
+                        add(L.OP_BLOCK_ENTRY, ep, (x.t, e1.w, e1.scale, e1.bias, e2.w, e2.scale, e2.bias, t.t, idt.t),
+                            conv=True, keep=(x, t, idt, e1, e2))
+                    else:
+                        conv_op(w[prefix + ".conv1"], x, t, stride, 1, True)
+                        if ds:
+                            idt = pool.get(oh, ow, planes)
+                            conv_op(w[prefix + ".ds"], x, idt, stride, 0, False)
+                    y = pool.get(oh, ow, planes, cells=y_cells)
                     conv_op(w[prefix + ".conv2"], t, y, 1, 1, True, res=idt)
                     pool.put(t)
                 else:

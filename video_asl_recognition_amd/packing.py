@@ -75,3 +75,67 @@ def pack_linear(w: torch.Tensor, device, bias=None, k_phys: Optional[int] = None
     p = p.to(torch.bfloat16).contiguous().to(device)
     b = None if bias is None else bias.to(torch.float32).contiguous().to(device)
     return PackedConv(p, None, b, n, k_phys, (1, 1, 1), w_rows)
+
+
+# ---------------------------------------------------------------------------------------------
+# Stride-2 block entry (asl_block_entry_s2_bf16): weights in MFMA-fragment order, activations as cells
+# ---------------------------------------------------------------------------------------------
+# K steps of one 32-channel group, as (ky, kx): plane 0 (even row, even column) four taps, plane 1 two, plane 2 two,
+# plane 3 (the centre tap) one -- the order the kernel walks the planes of the cell tensor
+ENTRY_TAP_ORDER = ((0, 0), (0, 2), (2, 0), (2, 2), (0, 1), (2, 1), (1, 0), (1, 2), (1, 1))
+
+
+def _entry_row_order() -> torch.Tensor:
+    """channel (within a 128-channel tile) of MFMA row fr of fragment (wc, j): a lane's accumulators of fragments 2h and
+    2h+1 are then eight consecutive channels, which the kernel stores as one 16-byte vector"""
+    idx = torch.empty(2, 4, 16, dtype=torch.long)
+    for wc in range(2):
+        for j in range(4):
+            for fr in range(16):
+                idx[wc, j, fr] = wc * 64 + (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3)
+    return idx
+
+
+def _entry_fragments(wk: torch.Tensor) -> torch.Tensor:
+    """wk fp32 [cout, steps, 32] (per output channel: K steps of 32 input channels) -> bf16
+    [cout/128][steps][wc 2][j 4][lane 64][8] with lane = fq*16 + fr holding k = 8*fq .. 8*fq+7 of row (wc, j, fr)"""
+    cout, steps, _ = wk.shape
+    assert cout % 128 == 0
+    t = wk.reshape(cout // 128, 128, steps, 4, 8)                    # [tile][row][step][fq][8]
+    rows = _entry_row_order().reshape(-1)                            # (wc, j, fr) -> row
+    t = t[:, rows]                                                    # [tile][(wc j fr)][step][fq][8]
+    t = t.reshape(cout // 128, 2, 4, 16, steps, 4, 8).permute(0, 4, 1, 2, 5, 3, 6)   # [tile][step][wc][j][fq][fr][8]
+    return t.reshape(-1).to(torch.bfloat16).contiguous()
+
+
+def pack_entry_conv(w: torch.Tensor, device, scale=None, bias=None) -> PackedConv:
+    """3x3 stride-2 conv weights [cout, cin, 3, 3] (cin % 32 == 0, cout % 128 == 0) for asl_block_entry_s2_bf16"""
+    w = w.to(torch.float32)
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and cin % 32 == 0 and cout % 128 == 0
+    taps = torch.stack([w[:, :, ky, kx] for ky, kx in ENTRY_TAP_ORDER], 1)          # [cout][9][cin]
+    wk = taps.reshape(cout, 9, cin // 32, 32).permute(0, 2, 1, 3).reshape(cout, 9 * (cin // 32), 32)   # step = 9*group + tap
+    return PackedConv(_entry_fragments(wk).to(device), scale, bias, cout, cin, (1, 3, 3), cout)
+
+
+def pack_entry_ds(w: torch.Tensor, device, scale=None, bias=None) -> PackedConv:
+    """1x1 stride-2 downsample weights [cout, cin, 1, 1] for asl_block_entry_s2_bf16: one K step per 32-channel group"""
+    w = w.to(torch.float32)
+    cout, cin = w.shape[:2]
+    assert tuple(w.shape[2:]) == (1, 1) and cin % 32 == 0 and cout % 128 == 0
+    wk = w.reshape(cout, cin // 32, 32)
+    return PackedConv(_entry_fragments(wk).to(device), scale, bias, cout, cin, (1, 1, 1), cout)
+
+
+def to_cells(x_halo: torch.Tensor) -> torch.Tensor:
+    """halo-1 NHWC image [n, H+2, W+2, C] (H, W even) -> space-to-depth cell tensor [n, (H+2)/2, (W+2)/2, 4, C]:
+    pixel (Y, X) in cell (Y>>1, X>>1), plane (Y&1)*2 + (X&1)"""
+    n, hp, wp, c = x_halo.shape
+    assert hp % 2 == 0 and wp % 2 == 0
+    return x_halo.reshape(n, hp // 2, 2, wp // 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, hp // 2, wp // 2, 4, c).contiguous()
+
+
+def from_cells(x2: torch.Tensor) -> torch.Tensor:
+    """inverse of to_cells"""
+    n, hc, wc, _, c = x2.shape
+    return x2.reshape(n, hc, wc, 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * hc, 2 * wc, c).contiguous()
