@@ -147,7 +147,10 @@ def main():
                 traffic = round(step_bytes / launches)
                 hbm_gbps = round(step_bytes / step_s / 1e9, 1)
                 mfma_busy = ctr.get("mfma_busy")
-        pre = time_with_preprocess(model, B, T, args.steps, args.warmup, dev)
+        try:
+            pre = time_with_preprocess(model, B, T, args.steps, args.warmup, dev)
+        except Exception as e:          # the secondary figure must never cost the headline line
+            pre = {"value": None, "unit": "clips/s", "error": f"{type(e).__name__}: {e}"[:200]}
         result = {
             "metric": "clips/sec end-to-end (T=64, 224x224, bf16)",
             "value": round(clips_per_s, 2),
