@@ -70,14 +70,15 @@ def algorithmic_per_clip(name, T):
 
 
 def main():
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     cases = [("tiny", 2, 8), ("resnet18_mean", 8, 32), ("resnet18_mean", 4, 64), ("resnet18_mean", 20, 64),
              ("i3d", 4, 64), ("i3d", 16, 64), ("resnet50_bilstm", 4, 64), ("resnet50_bilstm", 16, 64),
              ("twostream_transformer", 2, 128), ("twostream_transformer", 8, 128)]
     cache = {}
     for name, B, T in cases:
         spec = SPECS[name]
-        chunk = 640 if name in ("resnet18_mean", "twostream_transformer") else 256
+        # 640-frame chunks for the ResNet-18 configurations (as bench.py); the model's own default otherwise
+        chunk = 640 if name in ("resnet18_mean", "twostream_transformer") else None
         m = AslClipModel(spec, seed=0, frames_per_chunk=chunk)
         g = torch.Generator(device="cuda").manual_seed(0)
         clips = torch.randn(B, T, 3, spec.size, spec.size, generator=g, device="cuda").to(torch.bfloat16)
