@@ -221,6 +221,8 @@ typedef struct asl_conv3d_params {
     int32_t out_halo_d, out_halo, out_ctot, out_coff;
     int32_t relu;
     int32_t w_rows;
+    int32_t variant;                 /* ASL_CONV_AUTO, or ASL_CONV_GATHER / ASL_CONV_PP to force a kernel (3x3x3 / stride 1 / pad 1
+                                        with cin >= 64 and cout % 8 == 0 runs on the 3-D instance of the large-tile kernel) */
 } asl_conv3d_params;
 
 int asl_conv3d_ndhwc_bf16(const asl_conv3d_params* p, const void* x, const void* w,

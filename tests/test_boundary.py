@@ -38,7 +38,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(L.Conv2dParams) == 20 * 4 and C.sizeof(L.EntryParams) == 9 * 4
     assert C.sizeof(L.Op) == 8 + 8 + 10 * 8 + 8 * 4 + 6 * 4
     assert C.sizeof(L.StemParams) == 12 * 4
-    assert C.sizeof(L.Conv3dParams) == 21 * 4
+    assert C.sizeof(L.Conv3dParams) == 22 * 4
     assert C.sizeof(L.LinearParams) == 10 * 4
     assert C.sizeof(L.LstmParams) == 7 * 4 and C.sizeof(L.AttnParams) == 6 * 4
     assert C.sizeof(L.Pool3dParams) == 18 * 4

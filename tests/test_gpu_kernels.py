@@ -272,6 +272,64 @@ def test_fused_basic_block_cell_output(gpu, n, h, w):
                                           _p(p2.bias), _p(y_cells), None) == L.ASL_ENOTSUP
 
 
+# 3x3x3 / stride 1 / pad 1 convolutions (I3D's Unit3D), generic gather-GEMM and the 3-D instance of the 8-wave large-tile
+# kernel: tiles cut mid-row and mid-plane, a short last tile per clip, channel counts that are not whole 128-channel tiles,
+# a slice of a wider (concatenated) output tensor, one clip and several
+CONV3D_CASES = [
+    # n, d, h, w, cin, cout, out_ctot, out_coff
+    (2, 8, 28, 28, 96, 128, 128, 0),
+    (3, 4, 14, 14, 128, 208, 512, 192),
+    (2, 6, 7, 7, 192, 384, 384, 0),
+    (1, 5, 12, 17, 64, 192, 192, 0),
+    (2, 3, 20, 20, 160, 320, 832, 256),
+    (5, 2, 7, 7, 64, 48, 64, 16),
+]
+
+
+@pytest.mark.parametrize("variant", ["CONV_GATHER", "CONV_PP"])
+@pytest.mark.parametrize("n,d,h,w,cin,cout,ctot,coff", CONV3D_CASES)
+def test_conv3d_3x3x3(gpu, variant, n, d, h, w, cin, cout, ctot, coff):
+    from video_asl_recognition_amd import _lib as L
+    from video_asl_recognition_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(d * 100 + cin)
+    x = _bf16(torch.randn(n, cin, d, h, w, generator=g))
+    wt = _bf16(torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (cin * 27)) ** 0.5)
+    scale = torch.empty(cout).uniform_(0.5, 1.5, generator=g)
+    bias = torch.empty(cout).normal_(0, 0.1, generator=g)
+    ref = F.relu(F.conv3d(x, wt, None, 1, 1) * scale.view(1, -1, 1, 1, 1) + bias.view(1, -1, 1, 1, 1))
+    pc = pack_conv(wt, "cuda", scale=scale.cuda(), bias=bias.cuda())
+    xd = F.pad(x.permute(0, 2, 3, 4, 1), (0, 0, 1, 1, 1, 1, 1, 1)).to(torch.bfloat16).contiguous().cuda()
+    yd = torch.full((n, d + 2, h + 2, w + 2, ctot), 5.0, dtype=torch.bfloat16, device="cuda")
+    p = L.Conv3dParams(n=n, d=d, h=h, w=w, cin=cin, in_halo_d=1, in_halo=1, cout=cout, kd=3, kh=3, kw=3, stride_d=1, stride=1,
+                       pad_d=1, pad=1, out_halo_d=1, out_halo=1, out_ctot=ctot, out_coff=coff, relu=1, w_rows=pc.w_rows,
+                       variant=getattr(L, variant))
+    args = (C.byref(p), _p(xd), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(yd), None)
+    L.check(L.lib.asl_conv3d_ndhwc_bf16(*args), "conv3d")
+    torch.cuda.synchronize()
+    got = yd[:, 1:-1, 1:-1, 1:-1, coff:coff + cout].float().cpu().permute(0, 4, 1, 2, 3)
+    _assert_bf16_close(got, ref)
+    # nothing outside the slice and the interior was written
+    assert bool((yd[:, 0] == 5.0).all()) and bool((yd[:, :, :, -1] == 5.0).all()), "halo was written"
+    if coff:
+        assert bool((yd[..., :coff] == 5.0).all()), "channels before the slice were written"
+    if coff + cout < ctot:
+        assert bool((yd[..., coff + cout:] == 5.0).all()), "channels behind the slice were written"
+    y1 = yd.clone()
+    L.check(L.lib.asl_conv3d_ndhwc_bf16(*args), "conv3d")
+    torch.cuda.synchronize()
+    assert torch.equal(y1, yd), "two launches on the same input differ"
+
+
+def test_conv3d_forced_large_tile_kernel_refuses_what_it_cannot_run(gpu):
+    from video_asl_recognition_amd import _lib as L
+    x = torch.zeros(1, 4, 6, 6, 32, dtype=torch.bfloat16, device="cuda")
+    wz = torch.zeros(128, 27 * 32, dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(1, 4, 6, 6, 64, dtype=torch.bfloat16, device="cuda")
+    p = L.Conv3dParams(n=1, d=2, h=4, w=4, cin=32, in_halo_d=1, in_halo=1, cout=64, kd=3, kh=3, kw=3, stride_d=1, stride=1,
+                       pad_d=1, pad=1, out_halo_d=1, out_halo=1, out_ctot=64, out_coff=0, relu=1, w_rows=128, variant=L.CONV_PP)
+    assert L.lib.asl_conv3d_ndhwc_bf16(C.byref(p), _p(x), _p(wz), None, None, _p(y), None) == L.ASL_ENOTSUP   # 32 input channels
+
+
 # fused 64-channel BasicBlock: strips of 7 rows on 56x56; a last strip shorter than the others; rows wider and
 # narrower than a 32-pixel tile; more strips than CUs (several per persistent workgroup); an image smaller than
 # one strip; output halo 0 and 2

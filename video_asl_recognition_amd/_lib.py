@@ -57,7 +57,7 @@ class StemPoolParams(C.Structure):
 class Conv3dParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "d", "h", "w", "cin", "in_halo_d", "in_halo", "cout", "kd", "kh", "kw", "stride_d", "stride",
-        "pad_d", "pad", "out_halo_d", "out_halo", "out_ctot", "out_coff", "relu", "w_rows")]
+        "pad_d", "pad", "out_halo_d", "out_halo", "out_ctot", "out_coff", "relu", "w_rows", "variant")]
 
 
 class LinearParams(C.Structure):

@@ -119,7 +119,7 @@ extern "C" int asl_conv3d_ndhwc_bf16(const asl_conv3d_params* p, const void* x, 
     if (oplane > 0x7fffffffLL) return ASL_EINVAL;
     g.out.sn = oplane * odp; g.out.sd = (int32_t)oplane; g.out.sh = owp * p->out_ctot; g.out.sw = p->out_ctot;
     g.out.off0 = (int32_t)(p->out_halo_d * oplane) + (p->out_halo * owp + p->out_halo) * p->out_ctot + p->out_coff;
-    g.relu = p->relu; g.out_f32 = 0; g.w_rows = p->w_rows;
+    g.relu = p->relu; g.out_f32 = 0; g.w_rows = p->w_rows; g.variant = p->variant;
     g.x_elems = (int64_t)p->n * g.in.sn;
     g.y_elems = (int64_t)p->n * g.out.sn;
     return asl_gather_gemm_bf16(&g, x, w, scale, bias, nullptr, y, stream);

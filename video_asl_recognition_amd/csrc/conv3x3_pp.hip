@@ -16,6 +16,11 @@
 //    a raw s_barrier swaps the roles.
 //
 // MFMA orientation and weight packing are those of gather_gemm.hip.
+//
+// KD = 3 instance: 3x3x3 / stride 1 / pad 1 on halo'd NDHWC.  Depth planes of a clip lie behind one another exactly as
+// the images of a 2-D batch do, so the patch of a run of output pixels for ONE depth tap is the 2-D patch shifted by
+// whole planes: K walks (half-chunk, depth tap) pairs of nine steps each -- 27 taps at constant LDS offsets -- and
+// everything else is the 2-D kernel.  Tiles never cross a clip (the halo planes between clips would not fit a patch).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -51,7 +56,7 @@ struct PpShape {
     static_assert(PPW >= 1 && PPW <= 7 && WPW >= 1, "piece counts");
 };
 
-template <int FM_>
+template <int FM_, int KD>
 __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_kernel(const PatchArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using S = PpShape<FM_>;
@@ -79,23 +84,42 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         lbid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int tn = lbid % a.tiles_n, tm = lbid / a.tiles_n;
-    const int m0 = tm * a.bmv;
     const int HW = a.H * a.W;
+    int m0, mend;
+    if constexpr (KD == 3) {                            // tile tm = (clip, t): pixels t*bmv .. of that clip
+        const int clip = (int)fdiv(tm, a.dTPC), t = tm - clip * a.tiles_per_clip;
+        const int DHW = a.D * HW;
+        m0 = clip * DHW + t * a.bmv;
+        mend = (t + 1) * a.bmv < DHW ? m0 + a.bmv : (clip + 1) * DHW;
+    } else {
+        m0 = tm * a.bmv;
+        mend = (m0 + a.bmv < a.M ? m0 + a.bmv : a.M);
+    }
     auto centre = [&](int m) -> long long {             // halo'd, image-major pixel index of output pixel m
-        const int n = (int)fdiv(m, a.dOHW), r1 = m - n * HW;
-        const int y = (int)fdiv(r1, a.dOW), x = r1 - y * a.W;
-        return ((long long)n * a.Hp + y + a.in_halo) * a.Wp + x + a.in_halo;
+        if constexpr (KD == 3) {
+            const int n = (int)fdiv(m, a.dODHW), r = m - n * (a.D * HW);
+            const int d = (int)fdiv(r, a.dOHW), r1 = r - d * HW;
+            const int y = (int)fdiv(r1, a.dOW), x = r1 - y * a.W;
+            return (((long long)n * a.Dp + d + a.in_halo_d) * a.Hp + y + a.in_halo) * a.Wp + x + a.in_halo;
+        } else {
+            const int n = (int)fdiv(m, a.dOHW), r1 = m - n * HW;
+            const int y = (int)fdiv(r1, a.dOW), x = r1 - y * a.W;
+            return ((long long)n * a.Hp + y + a.in_halo) * a.Wp + x + a.in_halo;
+        }
     };
-    const int mend = (m0 + a.bmv < a.M ? m0 + a.bmv : a.M);
+    // P0: first patch pixel of the tile in the plane of the centre depth tap; the descriptor starts one plane earlier
+    const long long plane_px = KD == 3 ? (long long)a.Hp * a.Wp : 0;
     const long long P0 = centre(m0) - a.Wp - 1;
     const int NP = (int)(centre(mend - 1) + a.Wp + 1 - P0) + 1;       // <= PCAP (checked on the host)
     const int nhc = a.C >> 5;                                         // 32-channel half-chunks
-    const int nsteps = nhc * 9;
+    const int nq = nhc * KD;                                          // (half-chunk, depth tap) pairs, nine steps each
+    const int nsteps = nq * 9;
 
     // ---- DMA descriptors and per-lane source offsets ------------------------------------------
     const long long pix_bytes = 2LL * a.C;
-    const char* xbase = a.x + P0 * pix_bytes;
-    long long xrem = a.x_bytes - P0 * pix_bytes;
+    const char* xbase = a.x + (P0 - plane_px) * pix_bytes;
+    long long xrem = a.x_bytes - (P0 - plane_px) * pix_bytes;
+    const unsigned plane_bytes = (unsigned)(plane_px * pix_bytes);
     const unsigned xrec = (unsigned)(xrem > 0x7fffffffLL ? 0x7fffffffLL : xrem);
     __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, xrec, 0x00020000);
     const char* wbase = a.w + 2LL * (tn * S::TN) * a.wk;
@@ -108,12 +132,13 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
     // the 256-byte bank row is p & 15 whatever the chunk, so a fragment read of 16 consecutive pixels is
     // conflict-free with no address swizzle.  DMA lane -> pixel 16j + lane % 16, chunk lane / 16.
     const unsigned pvoff = (unsigned)((lane & 15) * pix_bytes + (lane >> 4) * 16);
-    auto dma_patch_piece = [&](int hc, int k) {         // piece (wave + 8k) of half-chunk hc
+    auto dma_patch_piece = [&](int q, int k) {          // piece (wave + 8k) of pair q = (half-chunk q / KD, depth tap q % KD)
         const int j = wave + 8 * k;
-        const bool live = hc < nhc && 16 * j < NP;      // else: zeros, into the piece itself or the spare last piece
+        const bool live = q < nq && 16 * j < NP;        // else: zeros, into the piece itself or the spare last piece
         const int jd = j < S::PIECES ? j : S::PIECES - 1;
-        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(16LL * j * pix_bytes + hc * 64));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(patches + (hc & 1) * S::PATCH_BYTES + jd * 1024),
+        const int hc = KD == 3 ? q / 3 : q, kt = q - hc * KD;
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(16LL * j * pix_bytes + hc * 64) + (unsigned)kt * plane_bytes);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(patches + (q & 1) * S::PATCH_BYTES + jd * 1024),
                                                  16, live ? pvoff : kOob, live ? so : 0u, 0, 0);
     };
     // weight piece q = wave * WPW + i covers tile rows 16q..16q+15 (64 B each); chunk swizzle (row & 8) ? 3 : 0
@@ -123,10 +148,11 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         const int row = (wave * WPW + i) * 16 + (lane >> 2);
         wvoff[i] = (unsigned)(2 * row * a.wk + 16 * ((lane & 3) ^ ((row & 8) ? 3 : 0)));
     }
-    auto dma_weights = [&](int s, int slot) {           // stage s = hc * 9 + tap -> ring slot s % RING
+    auto dma_weights = [&](int s, int slot) {           // stage s = q * 9 + tap -> ring slot s % RING
         const bool live = s < nsteps;
-        const int hc = s / 9, tap = s - 9 * hc;
-        const unsigned so = __builtin_amdgcn_readfirstlane(live ? (unsigned)(2 * (tap * a.C + hc * 32)) : 0u);
+        const int q = s / 9, tap = s - 9 * q;
+        const int hc = KD == 3 ? q / 3 : q, kt = q - hc * KD;
+        const unsigned so = __builtin_amdgcn_readfirstlane(live ? (unsigned)(2 * ((kt * 9 + tap) * a.C + hc * 32)) : 0u);
         char* dst = ring + slot * WST + wave * (WPW * 1024);
 #pragma unroll
         for (int i = 0; i < WPW; ++i)
@@ -246,7 +272,7 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
 #endif
     };
 #pragma unroll 1
-    for (hc = 0; hc < nhc; ++hc) {
+    for (hc = 0; hc < nq; ++hc) {                       // hc counts (half-chunk, depth tap) pairs
         pboff = lds0 + (int)(S::RING * S::WST) + (hc & 1) * S::PATCH_BYTES;
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
@@ -283,9 +309,19 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
                                                         // would carry 3 registers per fragment across the K loop
             const bool ok = m < mend;
             m = ok ? m : mend - 1;
-            const int n = (int)fdiv(m, a.dOHW), r1 = m - n * HW;
+            int n, r1;
+            long long od = 0;
+            if constexpr (KD == 3) {
+                n = (int)fdiv(m, a.dODHW);
+                const int r = m - n * (a.D * HW), d = (int)fdiv(r, a.dOHW);
+                r1 = r - d * HW;
+                od = (long long)d * a.out_sd;
+            } else {
+                n = (int)fdiv(m, a.dOHW);
+                r1 = m - n * HW;
+            }
             const int y = (int)fdiv(r1, a.dOW), x = r1 - y * a.W;
-            long long o = (long long)n * a.out_sn + (long long)y * a.out_sh + (long long)x * a.out_sw + a.out_off0 + ch0;
+            long long o = (long long)n * a.out_sn + od + (long long)y * a.out_sh + (long long)x * a.out_sw + a.out_off0 + ch0;
             if (a.out_s2d)          // cell layout for a stride-2 consumer: cell ((y+1)>>1, (x+1)>>1), plane by the parities
                 o = (long long)n * a.out_sn + (long long)((y + 1) >> 1) * a.out_sh + (long long)((x + 1) >> 1) * a.out_sw +
                     (((y + 1) & 1) * 2 + ((x + 1) & 1)) * a.out_s2d + a.out_off0 + ch0;
@@ -306,8 +342,11 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
                         rv[hh][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, re[i] == kOobOff ? kOobOff : re[i] + (h + hh) * 64, 0, 0);
             }
             f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, bi0 = {0.f, 0.f, 0.f, 0.f}, bi1 = bi0;
-            if (a.scale) { sc0 = *(const f32x4*)(a.scale + ch0 + h * 32); sc1 = *(const f32x4*)(a.scale + ch0 + h * 32 + 4); }
-            if (a.bias) { bi0 = *(const f32x4*)(a.bias + ch0 + h * 32); bi1 = *(const f32x4*)(a.bias + ch0 + h * 32 + 4); }
+            // the 3-D instance takes any channel count that is a multiple of 8: a lane whose 8 channels lie past N
+            // (weight rows there are zero padding) loads no constants and stores nothing
+            const bool ch_ok = KD == 1 || ch0 + h * 32 + 8 <= a.N;
+            if (a.scale && ch_ok) { sc0 = *(const f32x4*)(a.scale + ch0 + h * 32); sc1 = *(const f32x4*)(a.scale + ch0 + h * 32 + 4); }
+            if (a.bias && ch_ok) { bi0 = *(const f32x4*)(a.bias + ch0 + h * 32); bi1 = *(const f32x4*)(a.bias + ch0 + h * 32 + 4); }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const f32x4 v0 = acc[i][2 * h] * sc0 + bi0;
@@ -319,7 +358,7 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
                     ov[e] = f32_to_bf16(fmaxf(v0[e] + bf16_to_f32(r8[e]), floor_v));
                     ov[4 + e] = f32_to_bf16(fmaxf(v1[e] + bf16_to_f32(r8[4 + e]), floor_v));
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ov), yrs, oe[i] == kOobOff ? kOobOff : oe[i] + h * 64, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ov), yrs, (oe[i] == kOobOff || !ch_ok) ? kOobOff : oe[i] + h * 64, 0, 0);
             }
         }
     }
@@ -360,8 +399,34 @@ static int pp_launch(PatchArgs a, hipStream_t stream) {
     a.tiles_m = (a.M + a.bmv - 1) / a.bmv;
     a.tiles_n = (a.N + S::TN - 1) / S::TN;
     static unsigned char lds_set[64];
-    if (const int e = ensure_dynamic_lds((const void*)conv3x3_pp_kernel<FM_>, S::LDS, lds_set)) return e;
-    hipLaunchKernelGGL((conv3x3_pp_kernel<FM_>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), S::LDS, stream, a);
+    if (const int e = ensure_dynamic_lds((const void*)conv3x3_pp_kernel<FM_, 1>, S::LDS, lds_set)) return e;
+    hipLaunchKernelGGL((conv3x3_pp_kernel<FM_, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), S::LDS, stream, a);
+    return (int)hipGetLastError();
+}
+
+// 3x3x3 / stride 1 / pad 1 on halo'd NDHWC through the KD = 3 instance of the 256 x 128 kernel.  `a` carries the 2-D
+// fields of one depth plane (H, W, Hp, Wp, in_halo) plus D, Dp, in_halo_d, out_sd; n = clips.  Returns -1 when the
+// request does not fit (the caller falls back to the gather-GEMM).
+int try_launch_conv3x3x3_pp(PatchArgs a, int n, hipStream_t stream) {
+    using S = PpShape<4>;
+    if (a.variant != ASL_CONV_AUTO && a.variant != ASL_CONV_PP) return -1;
+    if (a.C % 32 || a.C < 64 || a.N % 8 || a.res || a.out_s2d) return -1;
+    if (a.y_bytes <= 0 || a.y_bytes >= 0xffffffffLL) return -1;
+    if (a.D <= 0 || a.in_halo_d < 1 || a.in_halo < 1 || a.Dp != a.D + 2 * a.in_halo_d) return -1;
+    if ((long long)a.Hp * a.Wp * 2 * a.C >= 0x40000000LL) return -1;            // one plane's bytes as a 32-bit DMA offset (x3)
+    // tiles of consecutive output pixels inside one clip: its depth planes lie like the images of a 2-D batch
+    a.bmv = pp_tile<4>(a.D, a.H, a.W, a.in_halo);
+    if (!a.bmv) return -1;
+    const long long dhw = (long long)a.D * a.H * a.W;
+    a.tiles_per_clip = (int)((dhw + a.bmv - 1) / a.bmv);
+    a.dTPC = make_fastdiv((unsigned)a.tiles_per_clip);
+    const long long tiles_m = (long long)n * a.tiles_per_clip;
+    a.tiles_n = (a.N + S::TN - 1) / S::TN;
+    if (tiles_m * a.tiles_n > 0x7fffffffLL) return -1;
+    a.tiles_m = (int)tiles_m;
+    static unsigned char lds_set[64];
+    if (const int e = ensure_dynamic_lds((const void*)conv3x3_pp_kernel<4, 3>, S::LDS, lds_set)) return e;
+    hipLaunchKernelGGL((conv3x3_pp_kernel<4, 3>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), S::LDS, stream, a);
     return (int)hipGetLastError();
 }
 

@@ -320,6 +320,27 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
                 return launch_conv3x3_patch(b, s);
         }
     }
+    // 3x3x3 / stride 1 / pad 1 on a halo'd NDHWC tensor: the 3-D instance of the 8-wave large-tile kernel
+    if (p->kd == 3 && p->kh == 3 && p->kw == 3 && (p->ck & 31) == 0 && !p->out_f32 && !p->res_f32 && !res && !p->out_s2d &&
+        p->tap_sw == p->ck && p->in.sw == p->ck && p->in.sh == p->tap_sh && p->in.sd == p->tap_sd && p->tap_sh % p->ck == 0 &&
+        p->tap_sh > 0 && p->tap_sd % p->tap_sh == 0 && p->in.sn % p->tap_sd == 0 && p->variant != ASL_CONV_GATHER) {
+        const int C = p->ck, Wp = p->tap_sh / C, Hp = p->tap_sd / p->tap_sh, Dp = (int)(p->in.sn / p->tap_sd);
+        const int halo = (Wp - p->ow) / 2, hd = (Dp - p->od) / 2;
+        if (halo >= 1 && hd >= 1 && Wp == p->ow + 2 * halo && Hp == p->oh + 2 * halo && Dp == p->od + 2 * hd &&
+            p->in.off0 == (((hd - 1) * Hp + (halo - 1)) * Wp + (halo - 1)) * C) {
+            PatchArgs b = {};
+            b.x = a.x; b.w = a.w; b.scale = a.scale; b.bias = a.bias; b.res = nullptr; b.y = a.y;
+            b.M = a.M; b.N = a.N; b.H = p->oh; b.W = p->ow; b.Hp = Hp; b.Wp = Wp; b.in_halo = halo;
+            b.D = p->od; b.Dp = Dp; b.in_halo_d = hd; b.out_sd = a.out_sd;
+            b.C = C; b.nchunks = C / 64; b.bmv = 0; b.wk = a.wk; b.x_bytes = a.x_bytes; b.w_bytes = a.w_bytes;
+            b.y_bytes = 2 * p->y_elems; b.res_bytes = 0;
+            b.out_sn = a.out_sn; b.out_sh = a.out_sh; b.out_sw = a.out_sw; b.out_off0 = a.out_off0;
+            b.relu = a.relu; b.stamps = nullptr; b.variant = p->variant; b.out_s2d = 0;
+            b.dOW = a.dOW; b.dOHW = a.dOHW; b.dODHW = a.dODHW;
+            const int r3 = try_launch_conv3x3x3_pp(b, p->nb, s);
+            if (r3 >= 0) return r3;
+        }
+    }
     if (p->variant > ASL_CONV_GATHER || p->out_s2d) return ASL_ENOTSUP;   // the forced kernel / the cell output does not fit this request
     if (p->ck % 64 == 0) {
         a.ksteps_per_tap = p->ck / 64;

@@ -32,6 +32,11 @@ struct PatchArgs {
     unsigned long long* stamps;   // diagnostic builds only (ASL_STAMPS): 5 s_memtime stamps per workgroup
     int stagger_ticks;     // one-time start delay (100 MHz ticks) of the second resident workgroup set
     int variant;           // ASL_CONV_* requested by the caller (0: the library chooses)
+    // 3x3x3 convolutions (conv3x3_pp's KD = 3 instance only): NDHWC input [n][D + 2*in_halo_d][Hp][Wp][C], output depth D
+    int D, Dp, in_halo_d;  // depth, halo'd depth, depth halo (>= 1); M = n * D * H * W, dODHW divides by D*H*W
+    int out_sd;            // element stride of one output depth plane
+    int tiles_per_clip;    // tiles never cross a clip: tile = clip * tiles_per_clip + t, pixels t*bmv .. of that clip
+    FastDiv dTPC;
     int out_s2d;           // 0, or the plane stride (elements) of a space-to-depth output: pixel (y, x) goes to cell
                            // ((y+1)>>1, (x+1)>>1) (strides out_sh, out_sw), plane ((y+1)&1)*2 + ((x+1)&1); conv3x3_pp only
 };
@@ -46,6 +51,7 @@ int patch_conv_tile(int n, int h, int w, int in_halo);
 // large-tile kernel (conv3x3_pp.hip): returns -1 when the request does not fit it
 int try_launch_conv3x3_wide(PatchArgs a, int n, hipStream_t stream);
 int try_launch_conv3x3_pp(PatchArgs a, int n, hipStream_t stream);
+int try_launch_conv3x3x3_pp(PatchArgs a, int n, hipStream_t stream);
 // persistent 64 -> 64 channel kernel (conv3x3_c64.hip): returns -1 when the request does not fit it
 int try_launch_conv3x3_c64(PatchArgs a, int n, hipStream_t stream);
 int launch_conv3x3_patch(PatchArgs a, hipStream_t stream);
