@@ -98,6 +98,14 @@ typedef struct asl_gemm_params {
                                         ((w+1)>>1)*out.sw + (((h+1)&1)*2 + ((w+1)&1))*out.sd + out.off0 (out.sd, unused by a
                                         2-D output otherwise, is the plane stride); only the 3x3 large-tile kernel
                                         (ASL_CONV_PP) writes it: other requests return ASL_ENOTSUP */
+    int32_t split_out;               /* 0, or 1: split-precision epilogue (the parity mode).  The bf16 output is written as two
+                                        halves -- hi = bf16(v) at the usual place, lo = bf16(v - hi) out_lo elements further
+                                        on -- and a bf16 residual is read as hi + lo (its lo half res_lo elements further
+                                        on).  hi + lo carries the fp32 value to ~16 mantissa bits; a consumer reads both
+                                        halves as 2 x ck input channels against weights duplicated along K.  Gather-GEMM
+                                        only (other forced variants: ASL_ENOTSUP) */
+    int32_t out_lo, res_lo;          /* element offsets of the lo halves (>= cout, multiples of 8) */
+    int32_t reserved;                /* must be 0 */
 } asl_gemm_params;
 
 int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, const void* w,
@@ -122,6 +130,11 @@ typedef struct asl_conv2d_params {
                                         asl_block_entry_s2_bf16); needs out_halo == 1, out_coff == 0, out_ctot == cout,
                                         even oh and ow, and a kernel that can write it (3x3/s1/p1, cin >= 128,
                                         cout % 128 == 0: ASL_ENOTSUP otherwise)            */
+    int32_t out_split;               /* 1: split-precision output and residual (parity mode, see asl_gemm_params.split_out):
+                                        y's hi half sits at channels [out_coff, out_coff + cout) and its lo half out_ctot / 2
+                                        channels further on (out_coff + cout <= out_ctot / 2); res likewise with res_ctot / 2.
+                                        The input needs no flag: its [hi | lo] halves are 2 x the logical channels, the
+                                        weights are packed duplicated along K (packing.pack_conv(..., split=True)) */
 } asl_conv2d_params;
 
 int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, const void* w,
@@ -194,6 +207,7 @@ typedef struct asl_stem_params {
     int32_t out_halo;
     int32_t relu;
     int32_t w_rows;
+    int32_t out_split;               /* 1: y has 2 * cout channels, [hi | lo] halves of the split-precision output */
 } asl_stem_params;
 
 int asl_stem_conv_bf16(const asl_stem_params* p, const void* x, const void* w,
@@ -263,6 +277,12 @@ int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, int s, int h
  * wherever a window overlaps the halo (true after ReLU): the zero halo then acts as -inf. */
 int asl_maxpool3x3s2_nhwc(const void* x, int n, int h, int w, int c, int in_halo,
                           void* y, int out_halo, asl_stream_t stream);
+
+/* The same pool on a split-precision tensor (parity mode): x [n][h+2*in_halo][w+2*in_halo][2c] with channels [0, c) the hi
+ * and [c, 2c) the lo halves (asl_gemm_params.split_out); the maximum is taken over hi + lo in fp32 and written as a
+ * hi / lo pair into y [n][oh+2*out_halo][ow+2*out_halo][2c].  c % 8 == 0, values >= 0. */
+int asl_maxpool3x3s2_split_nhwc(const void* x, int n, int h, int w, int c, int in_halo,
+                                void* y, int out_halo, asl_stream_t stream);
 
 /* nn.MaxPool3d((kd,kh,kw), (sd,sh,sw), pad = (pd,ph,pw)) on halo'd NDHWC bf16, inputs >= 0. */
 typedef struct asl_pool3d_params {
@@ -388,6 +408,7 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
  *   ASL_OP_HEAD          NULL                    x, w, b, y                              m, f, c
  *   ASL_OP_BASIC_BLOCK   asl_block_params*       x, w1, scale1, bias1, w2, scale2, bias2, y
  *   ASL_OP_BLOCK_ENTRY   asl_entry_params*       x2, w, scale, bias, w_ds, scale_ds, bias_ds, y, y_ds
+ *   ASL_OP_MAXPOOL_SPLIT NULL                    x, y                                    n, h, w, c, in_halo, out_halo
  *
  * Returns ASL_OK, or the first failing op's return code with its index in *failed (if failed != NULL); ops
  * before it have been issued, ops after it have not.  ASL_EINVAL for an unknown kind, a stream index outside
@@ -395,7 +416,7 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
 enum {
     ASL_OP_CONV2D = 1, ASL_OP_STEM_CONV = 2, ASL_OP_STEM_POOL = 3, ASL_OP_CONV3D = 4, ASL_OP_LINEAR = 5,
     ASL_OP_MAXPOOL3D = 6, ASL_OP_MAXPOOL = 7, ASL_OP_AVGPOOL = 8, ASL_OP_PACK_CLIPS = 9, ASL_OP_PREPROCESS = 10,
-    ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12, ASL_OP_BASIC_BLOCK = 13, ASL_OP_BLOCK_ENTRY = 14
+    ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12, ASL_OP_BASIC_BLOCK = 13, ASL_OP_BLOCK_ENTRY = 14, ASL_OP_MAXPOOL_SPLIT = 15
 };
 
 typedef struct asl_op {

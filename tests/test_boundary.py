@@ -35,14 +35,14 @@ def test_version_and_strerror():
 def test_struct_sizes_match_header_layout():
     from video_asl_recognition_amd import _lib as L
     assert C.sizeof(L.Geom) == 24 and C.sizeof(L.BlockParams) == 9 * 4
-    assert C.sizeof(L.Conv2dParams) == 20 * 4 and C.sizeof(L.EntryParams) == 9 * 4
+    assert C.sizeof(L.Conv2dParams) == 21 * 4 and C.sizeof(L.EntryParams) == 9 * 4
     assert C.sizeof(L.Op) == 8 + 8 + 10 * 8 + 8 * 4 + 6 * 4
-    assert C.sizeof(L.StemParams) == 12 * 4
+    assert C.sizeof(L.StemParams) == 13 * 4
     assert C.sizeof(L.Conv3dParams) == 22 * 4
     assert C.sizeof(L.LinearParams) == 10 * 4
     assert C.sizeof(L.LstmParams) == 7 * 4 and C.sizeof(L.AttnParams) == 6 * 4
     assert C.sizeof(L.Pool3dParams) == 18 * 4
-    assert C.sizeof(L.GemmParams) == 12 * 4 + 3 * 24 + 4 * 4 + 3 * 8 + 2 * 4
+    assert C.sizeof(L.GemmParams) == 12 * 4 + 3 * 24 + 4 * 4 + 3 * 8 + 6 * 4
 
 
 def test_bad_geometry_is_rejected_without_launch():

@@ -69,6 +69,23 @@ def test_resnet18_cell_entry_path_matches_oracle(gpu):
     assert rel_l2(y, y0) <= 3e-4
 
 
+@pytest.mark.parametrize("name,B,T,size", [("resnet18_mean", 2, 8, 224), ("resnet50_bilstm", 2, 6, 224)])
+def test_parity_mode_matches_oracle_more_closely(gpu, name, B, T, size):
+    """parity mode (hi + lo activation pairs through every convolution): same oracle, an error several times below
+    the default path's"""
+    om, m = _model(name, parity_mode=True)
+    _, m0 = _model(name)
+    clips = O.make_clips(B, T, size, 0)
+    y, y0 = m(clips.cuda()).cpu(), m0(clips.cuda()).cpu()
+    with torch.no_grad():
+        ref = om(clips)
+    kinds = [int(r["op"].kind) for r in m._plan[0]["ops"]]
+    assert 15 in kinds and 13 not in kinds       # ASL_OP_MAXPOOL_SPLIT present, no fused ASL_OP_BASIC_BLOCK
+    e, e0 = rel_l2(y, ref), rel_l2(y0, ref)
+    assert e <= REL_TOL and torch.equal(y.argmax(1), ref.argmax(1))
+    assert e <= 0.5 * e0 + 2e-5, (e, e0)
+
+
 def test_resnet18_bf16_input_equals_fp32_input(gpu):
     """inputs are bf16-representable, so handing them over as bf16 must change nothing"""
     _, m = _model("resnet18_mean")

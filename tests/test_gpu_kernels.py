@@ -151,6 +151,113 @@ def _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu, variant=0):
     assert torch.equal(y1, yd), "two launches on the same input differ"
 
 
+# Parity mode: activations as [hi | lo] bf16 halves (2 * C channels per pixel), weights duplicated along K, the output
+# written as hi = bf16(v), lo = bf16(v - hi).  hi + lo carries ~16 mantissa bits, so the result is held to 2^-14 of the
+# fp32 convolution of the (hi + lo) inputs -- 64 times tighter than the single-bf16 kernels' bar.
+def _split(x_nchw, halo):
+    hi = x_nchw.to(torch.bfloat16)
+    lo = (x_nchw - hi.float()).to(torch.bfloat16)
+    x = torch.cat([hi, lo], 1).permute(0, 2, 3, 1)
+    return F.pad(x, (0, 0, halo, halo, halo, halo)).contiguous().cuda(), hi.float() + lo.float()
+
+
+def _unsplit(y, halo, c):
+    y = y.float().cpu()
+    if halo:
+        y = y[:, halo:-halo, halo:-halo]
+    return (y[..., :c] + y[..., c:]).permute(0, 3, 1, 2)
+
+
+SPLIT_CASES = [
+    # n, h, w, cin, cout, k, stride, pad, res, relu
+    (2, 56, 56, 64, 64, 3, 1, 1, True, True),
+    (3, 28, 28, 64, 128, 3, 2, 1, False, True),
+    (3, 28, 28, 64, 128, 1, 2, 0, False, False),
+    (2, 14, 14, 256, 1024, 1, 1, 0, True, True),
+    (5, 7, 7, 512, 512, 3, 1, 1, True, True),
+    (6, 20, 20, 192, 200, 3, 1, 1, True, True),      # channel count between tiles: the tail path writes both halves too
+    (9, 7, 7, 96, 40, 1, 1, 0, True, False),
+    (1, 1, 1, 64, 64, 1, 1, 0, False, False),
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,res,relu", SPLIT_CASES)
+def test_conv2d_split_precision(gpu, n, h, w, cin, cout, k, stride, pad, res, relu):
+    from video_asl_recognition_amd import _lib as L
+    from video_asl_recognition_amd.packing import pack_conv
+    g = torch.Generator().manual_seed(h * 17 + cout)
+    xd, x = _split(torch.randn(n, cin, h, w, generator=g), 1)
+    wt = _bf16(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    scale = torch.empty(cout).uniform_(0.5, 1.5, generator=g)
+    bias = torch.empty(cout).normal_(0, 0.1, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), None, stride, pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    oh, ow = ref.shape[2:]
+    rd = None
+    if res:
+        rd, r = _split(torch.randn(n, cout, oh, ow, generator=g), 1)
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    ref = ref.float()
+    pc = pack_conv(wt, "cuda", scale=scale.cuda(), bias=bias.cuda(), split=True)
+    assert pc.cin_phys == 2 * cin
+    yd = torch.zeros(n, oh + 2, ow + 2, 2 * cout, dtype=torch.bfloat16, device="cuda")
+    p = L.Conv2dParams(n=n, h=h, w=w, cin=2 * cin, in_halo=1, cout=cout, kh=k, kw=k, stride=stride, pad=pad, out_halo=1,
+                       out_ctot=2 * cout, out_coff=0, res_halo=1, res_ctot=2 * cout, res_coff=0, relu=int(relu),
+                       w_rows=pc.w_rows, variant=L.CONV_GATHER, out_split=1)
+    L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(p), _p(xd), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(rd), _p(yd), None))
+    torch.cuda.synchronize()
+    assert yd[:, 0].abs().sum() == 0 and yd[:, :, 0].abs().sum() == 0, "halo was written"
+    got = _unsplit(yd, 1, cout)
+    tol = 2.0 ** -14 * ref.abs().clamp_min(0.25)        # floor: fp32 accumulation over up to 9 216 O(1) terms, ~1e-5 absolute
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} beyond 2^-14; max abs err {(got - ref).abs().max():.3e}"
+    # the hi half alone is the ordinary bf16 result
+    _assert_bf16_close(_unhalo(yd, 1)[:, :cout], ref)
+
+
+def test_conv2d_split_rejects(gpu):
+    from video_asl_recognition_amd import _lib as L
+    x = torch.zeros(1, 10, 10, 128, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(128, 9 * 128, dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(1, 10, 10, 128, dtype=torch.bfloat16, device="cuda")
+    base = dict(n=1, h=8, w=8, cin=128, in_halo=1, cout=64, kh=3, kw=3, stride=1, pad=1, out_halo=1, out_ctot=128,
+                out_coff=0, res_halo=0, res_ctot=0, res_coff=0, relu=1, w_rows=128, out_split=1)
+    for bad in (dict(variant=L.CONV_PP), dict(out_ctot=127), dict(out_s2d=1)):
+        p = L.Conv2dParams(**{**base, **bad})
+        with pytest.raises(RuntimeError):
+            L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(p), _p(x), _p(w), None, None, None, _p(y), None))
+
+
+def test_stem_and_maxpool_split_precision(gpu):
+    from video_asl_recognition_amd import _lib as L
+    from video_asl_recognition_amd.packing import pack_stem
+    g = torch.Generator().manual_seed(11)
+    n, s = 3, 64
+    clips = _bf16(torch.randn(n, 3, s, s, generator=g))
+    wt = _bf16(torch.randn(64, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5)
+    scale = torch.empty(64).uniform_(0.5, 1.5, generator=g)
+    bias = torch.empty(64).normal_(0, 0.1, generator=g)
+    ref = F.relu(F.conv2d(clips.double(), wt.double(), None, 2, 3) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)).float()
+    x0 = torch.zeros(n, s + 6, s + 6, 4, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib.asl_pack_clips(_p(clips.cuda()), 1, n, s, 3, _p(x0), None))
+    pc = pack_stem(wt, "cuda", scale.cuda(), bias.cuda())
+    yd = torch.zeros(n, s // 2 + 2, s // 2 + 2, 128, dtype=torch.bfloat16, device="cuda")
+    p = L.StemParams(n=n, h=s, w=s, in_halo=3, cout=64, kh=7, kw=7, stride=2, pad=3, out_halo=1, relu=1, w_rows=pc.w_rows,
+                     out_split=1)
+    L.check(L.lib.asl_stem_conv_bf16(C.byref(p), _p(x0), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(yd), None))
+    torch.cuda.synchronize()
+    got = _unsplit(yd, 1, 64)
+    assert ((got - ref).abs() <= 2.0 ** -14 * ref.abs().clamp_min(0.25)).all(), (got - ref).abs().max()
+    # max-pool of the pairs: the pair with the largest hi + lo wins, and both its halves are copied (so the pooled
+    # value is exactly the max over the window of the values the pairs stand for)
+    zd = torch.zeros(n, s // 4 + 2, s // 4 + 2, 128, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib.asl_maxpool3x3s2_split_nhwc(_p(yd), n, s // 2, s // 2, 64, 1, _p(zd), 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(_unsplit(zd, 1, 64), F.max_pool2d(got, 3, 2, 1))
+    assert zd[:, 0].abs().sum() == 0 and zd[:, :, -1].abs().sum() == 0
+
+
 # Stride-2 block entry on the cell tensor: the three ResNet shapes (tiles straddling rows and images, several channel
 # tiles, a short last tile), one and ten channel groups, rows wider than a fragment, a single mostly idle tile, no
 # downsample

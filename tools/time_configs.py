@@ -73,13 +73,16 @@ def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     cases = [("tiny", 2, 8), ("resnet18_mean", 8, 32), ("resnet18_mean", 4, 64), ("resnet18_mean", 20, 64),
              ("i3d", 4, 64), ("i3d", 16, 64), ("resnet50_bilstm", 4, 64), ("resnet50_bilstm", 16, 64),
-             ("twostream_transformer", 2, 128), ("twostream_transformer", 8, 128)]
+             ("twostream_transformer", 2, 128), ("twostream_transformer", 8, 128),
+             # parity mode (hi + lo activation pairs, every conv on the gather-GEMM): what the tighter numerics cost
+             ("resnet18_mean", 20, 64, True), ("resnet50_bilstm", 16, 64, True)]
     cache = {}
-    for name, B, T in cases:
+    for name, B, T, *rest in cases:
+        parity_mode = bool(rest and rest[0])
         spec = SPECS[name]
         # 640-frame chunks for the ResNet-18 configurations (as bench.py); the model's own default otherwise
         chunk = 640 if name in ("resnet18_mean", "twostream_transformer") else None
-        m = AslClipModel(spec, seed=0, frames_per_chunk=chunk)
+        m = AslClipModel(spec, seed=0, frames_per_chunk=chunk, parity_mode=parity_mode)
         g = torch.Generator(device="cuda").manual_seed(0)
         clips = torch.randn(B, T, 3, spec.size, spec.size, generator=g, device="cuda").to(torch.bfloat16)
         kp = torch.rand(B, T, 21, 2, generator=g, device="cuda") if spec.temporal == "transformer" else None
@@ -95,7 +98,8 @@ def main():
             cache[(name, T)] = algorithmic_per_clip(name, T)
         fl, by = cache[(name, T)]
         tf = fl * B / dt
-        rec = {"config": name, "clips": B, "frames": T, "size": spec.size, "ms_per_forward": round(dt * 1e3, 3),
+        rec = {"config": name, "mode": "parity" if parity_mode else "default", "clips": B, "frames": T, "size": spec.size,
+               "ms_per_forward": round(dt * 1e3, 3),
                "clips_per_s": round(B / dt, 1), "algorithmic_gflop_per_clip": round(fl / 1e9, 2),
                "roofline": {"bound": "mfma", "achieved": round(tf / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                             "frac": round(tf / MFMA_PEAK, 4)},

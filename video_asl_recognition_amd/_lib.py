@@ -28,13 +28,14 @@ class GemmParams(C.Structure):
                 ("in_", Geom), ("out", Geom), ("res", Geom),
                 ("relu", C.c_int32), ("out_f32", C.c_int32), ("res_f32", C.c_int32), ("w_rows", C.c_int32),
                 ("x_elems", C.c_int64), ("y_elems", C.c_int64), ("res_elems", C.c_int64),
-                ("variant", C.c_int32), ("out_s2d", C.c_int32)]
+                ("variant", C.c_int32), ("out_s2d", C.c_int32),
+                ("split_out", C.c_int32), ("out_lo", C.c_int32), ("res_lo", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Conv2dParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n", "h", "w", "cin", "in_halo", "cout", "kh", "kw", "stride", "pad",
-        "out_halo", "out_ctot", "out_coff", "res_halo", "res_ctot", "res_coff", "relu", "w_rows", "variant", "out_s2d")]
+        "out_halo", "out_ctot", "out_coff", "res_halo", "res_ctot", "res_coff", "relu", "w_rows", "variant", "out_s2d", "out_split")]
 
 
 class BlockParams(C.Structure):
@@ -47,7 +48,7 @@ class EntryParams(C.Structure):
 
 class StemParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
-        "n", "h", "w", "in_halo", "cout", "kh", "kw", "stride", "pad", "out_halo", "relu", "w_rows")]
+        "n", "h", "w", "in_halo", "cout", "kh", "kw", "stride", "pad", "out_halo", "relu", "w_rows", "out_split")]
 
 
 class StemPoolParams(C.Structure):
@@ -81,7 +82,7 @@ class Op(C.Structure):
 
 
 (OP_CONV2D, OP_STEM_CONV, OP_STEM_POOL, OP_CONV3D, OP_LINEAR, OP_MAXPOOL3D, OP_MAXPOOL, OP_AVGPOOL, OP_PACK_CLIPS,
- OP_PREPROCESS, OP_MEAN_T, OP_HEAD, OP_BASIC_BLOCK, OP_BLOCK_ENTRY) = range(1, 15)
+ OP_PREPROCESS, OP_MEAN_T, OP_HEAD, OP_BASIC_BLOCK, OP_BLOCK_ENTRY, OP_MAXPOOL_SPLIT) = range(1, 16)
 
 
 class AttnParams(C.Structure):
@@ -116,6 +117,7 @@ _PROTOS = {
     "asl_pack_clips": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
     "asl_preprocess_u8": ([_P, _I, _I, _I, _I, _I, _F3, _F3, _P, _P, _P], C.c_int),
     "asl_maxpool3x3s2_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _I, _P], C.c_int),
+    "asl_maxpool3x3s2_split_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _I, _P], C.c_int),
     "asl_maxpool3d_ndhwc": ([C.POINTER(Pool3dParams), _P, _P, _P], C.c_int),
     "asl_avgpool_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P], C.c_int),
     "asl_mean_t_f32": ([_P, _I, _I, _I, _P, _P], C.c_int),

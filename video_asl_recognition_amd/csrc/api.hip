@@ -5,7 +5,7 @@
 
 #include "asl_hip.h"
 
-extern "C" int asl_version(void) { return 102; }
+extern "C" int asl_version(void) { return 103; }
 
 extern "C" const char* asl_strerror(int rc) {
     switch (rc) {
@@ -58,6 +58,11 @@ extern "C" int asl_conv2d_nhwc_bf16(const asl_conv2d_params* p, const void* x, c
     }
     g.relu = p->relu; g.out_f32 = 0; g.w_rows = p->w_rows; g.variant = p->variant;
     g.x_elems = (int64_t)p->n * g.in.sn;
+    if (p->out_split) {
+        if (p->out_split != 1 || p->out_s2d || (p->out_ctot & 15) || p->out_coff + p->cout > p->out_ctot / 2) return ASL_EINVAL;
+        if (res && ((p->res_ctot & 15) || p->res_coff + p->cout > p->res_ctot / 2)) return ASL_EINVAL;
+        g.split_out = 1; g.out_lo = p->out_ctot / 2; g.res_lo = res ? p->res_ctot / 2 : 0;
+    }
     return asl_gather_gemm_bf16(&g, x, w, scale, bias, res, y, stream);
 }
 
@@ -82,8 +87,11 @@ extern "C" int asl_stem_conv_bf16(const asl_stem_params* p, const void* x, const
     g.in.sn = (int64_t)hp * wp * 4; g.in.sd = 0; g.in.sh = p->stride * wp * 4; g.in.sw = p->stride * 4;
     g.in.off0 = ((p->in_halo - p->pad) * wp + (p->in_halo - p->pad)) * 4;
     const int owp = ow + 2 * p->out_halo, ohp = oh + 2 * p->out_halo;
-    g.out.sn = (int64_t)ohp * owp * p->cout; g.out.sd = 0; g.out.sh = owp * p->cout; g.out.sw = p->cout;
-    g.out.off0 = (p->out_halo * owp + p->out_halo) * p->cout;
+    if (p->out_split != 0 && p->out_split != 1) return ASL_EINVAL;
+    const int octot = p->out_split ? 2 * p->cout : p->cout;      // [hi | lo] halves of a split-precision output
+    g.out.sn = (int64_t)ohp * owp * octot; g.out.sd = 0; g.out.sh = owp * octot; g.out.sw = octot;
+    g.out.off0 = (p->out_halo * owp + p->out_halo) * octot;
+    if (p->out_split) { g.split_out = 1; g.out_lo = p->cout; }
     g.relu = p->relu; g.out_f32 = 0; g.w_rows = p->w_rows;
     g.x_elems = (int64_t)p->n * g.in.sn;
     g.y_elems = (int64_t)p->n * g.out.sn;
@@ -177,6 +185,9 @@ extern "C" int asl_run_ops(const asl_op* ops, int count, const asl_stream_t* str
                     break;
                 case ASL_OP_MAXPOOL:
                     rc = asl_maxpool3x3s2_nhwc(p[0], i[0], i[1], i[2], i[3], i[4], p[1], i[5], s);
+                    break;
+                case ASL_OP_MAXPOOL_SPLIT:
+                    rc = asl_maxpool3x3s2_split_nhwc(p[0], i[0], i[1], i[2], i[3], i[4], p[1], i[5], s);
                     break;
                 case ASL_OP_AVGPOOL:
                     rc = asl_avgpool_nhwc(p[0], i[0], i[1], i[2], i[3], i[4], (float*)p[1], p[2], i[5], i[6], s);

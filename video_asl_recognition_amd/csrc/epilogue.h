@@ -21,6 +21,7 @@ struct OutGeom {
     int res_sd, res_sh, res_sw, res_off0;
     int relu, out_f32;
     int res_f32;                       // residual is fp32 instead of bf16 (same geometry)
+    int out_lo, res_lo;                // split-precision epilogue: element offsets of the lo halves (see epilogue_store)
 };
 
 constexpr int kEpiRowBytes(int wtn) { return wtn * 4 + 16; }          // fp32 row + 16 B pad
@@ -43,7 +44,7 @@ struct EpiState {
     bool full;                                    // ch..ch+7 all < N
 };
 
-template <int FM, int FN>
+template <int FM, int FN, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_prepare(EpiState<FM, FN>& st, const OutGeom& g, int m_wave0, int ch_wave0,
                                                  int lane) {
     using S = EpiState<FM, FN>;
@@ -69,7 +70,7 @@ __device__ __forceinline__ void epilogue_prepare(EpiState<FM, FN>& st, const Out
             if (g.res) {
                 st.re[i][ps] = (long long)n * g.res_sn + (long long)d * g.res_sd + (long long)h * g.res_sh +
                                (long long)w_ * g.res_sw + g.res_off0 + st.ch;
-                if (ok && st.full && !g.res_f32) st.r8[i][ps] = *(const bf16x8*)(g.res + 2 * st.re[i][ps]);
+                if (!SPLIT && ok && st.full && !g.res_f32) st.r8[i][ps] = *(const bf16x8*)(g.res + 2 * st.re[i][ps]);
             }
         }
 }
@@ -77,7 +78,10 @@ __device__ __forceinline__ void epilogue_prepare(EpiState<FM, FN>& st, const Out
 // acc[i][j]: 16x16 tile (pixel fragment i, channel fragment j); lane holds channels 4*(lane>>4)..+3
 // of pixel (lane & 15).  `stage` is this wave's private LDS region of kEpiWaveBytes(FN*16) bytes; the
 // caller guarantees no other wave still reads the LDS it overlays.
-template <int FM, int FN>
+// SPLIT (the parity mode's split-precision activations): the bf16 output is written as two halves, hi = bf16(v) at the
+// usual place and lo = bf16(v - hi) out_lo elements further on, so hi + lo carries v to ~16 mantissa bits; a residual is
+// read the same way (its lo half res_lo elements further on) when it is used, not ahead of the K loop.
+template <int FM, int FN, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char* stage, const OutGeom& g,
                                                const EpiState<FM, FN>& st, int lane) {
     using S = EpiState<FM, FN>;
@@ -114,6 +118,17 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char*
                     v0 += *(const f32x4*)(g.res + 4 * st.re[i][ps]);
                     v1 += *(const f32x4*)(g.res + 4 * st.re[i][ps] + 16);
                 }
+                if constexpr (SPLIT) {
+                    if (g.res && !g.res_f32) {
+                        const bf16x8 rh = *(const bf16x8*)(g.res + 2 * st.re[i][ps]);
+                        const bf16x8 rl = *(const bf16x8*)(g.res + 2 * (st.re[i][ps] + g.res_lo));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v0[e] += bf16_to_f32(rh[e]) + bf16_to_f32(rl[e]);
+                            v1[e] += bf16_to_f32(rh[4 + e]) + bf16_to_f32(rl[4 + e]);
+                        }
+                    }
+                }
                 if (g.relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
@@ -126,6 +141,15 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char*
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ov[e] = f32_to_bf16(v0[e]); ov[4 + e] = f32_to_bf16(v1[e]); }
                     *(bf16x8*)(g.y + 2 * o) = ov;
+                    if constexpr (SPLIT) {
+                        bf16x8 lv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            lv[e] = f32_to_bf16(v0[e] - bf16_to_f32(ov[e]));
+                            lv[4 + e] = f32_to_bf16(v1[e] - bf16_to_f32(ov[4 + e]));
+                        }
+                        *(bf16x8*)(g.y + 2 * (o + g.out_lo)) = lv;
+                    }
                 }
             } else {
                 for (int e = 0; e < 8 && ch + e < g.N; ++e) {
@@ -134,9 +158,14 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char*
                     if (g.bias) t += g.bias[ch + e];
                     if (g.res) t += g.res_f32 ? *(const float*)(g.res + 4 * (st.re[i][ps] + e))
                                               : bf16_to_f32(*(const short*)(g.res + 2 * (st.re[i][ps] + e)));
+                    if (SPLIT && g.res && !g.res_f32) t += bf16_to_f32(*(const short*)(g.res + 2 * (st.re[i][ps] + g.res_lo + e)));
                     if (g.relu) t = fmaxf(t, 0.f);
                     if (g.out_f32) *(float*)(g.y + 4 * (o + e)) = t;
-                    else *(short*)(g.y + 2 * (o + e)) = f32_to_bf16(t);
+                    else {
+                        const short hv = f32_to_bf16(t);
+                        *(short*)(g.y + 2 * (o + e)) = hv;
+                        if (SPLIT) *(short*)(g.y + 2 * (o + g.out_lo + e)) = f32_to_bf16(t - bf16_to_f32(hv));
+                    }
                 }
             }
         }

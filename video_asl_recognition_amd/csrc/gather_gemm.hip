@@ -34,7 +34,7 @@ __device__ __forceinline__ int swz(int row) {
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+template <int BM, int BN, int BK, int WGM, int WGN, bool SPLIT = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub; the body uses device-only types
     constexpr int NW = WGM * WGN;
@@ -163,9 +163,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
     g.dOW = a.dOW; g.dOHW = a.dOHW; g.dODHW = a.dODHW;
     g.out_sn = a.out_sn; g.out_sd = a.out_sd; g.out_sh = a.out_sh; g.out_sw = a.out_sw; g.out_off0 = a.out_off0;
     g.res_sn = a.res_sn; g.res_sd = a.res_sd; g.res_sh = a.res_sh; g.res_sw = a.res_sw; g.res_off0 = a.res_off0;
-    g.relu = a.relu; g.out_f32 = a.out_f32; g.res_f32 = a.res_f32;
+    g.relu = a.relu; g.out_f32 = a.out_f32; g.res_f32 = a.res_f32; g.out_lo = a.out_lo; g.res_lo = a.res_lo;
     EpiState<FM, FN> est;
-    epilogue_prepare<FM, FN>(est, g, m0 + wm * WTM, tn * BN + wn * WTN, lane);
+    epilogue_prepare<FM, FN, SPLIT>(est, g, m0 + wm * WTM, tn * BN + wn * WTN, lane);
 
     const int nsteps = a.ntaps * a.ksteps_per_tap;
     stage(0);
@@ -195,12 +195,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
 
     // ---- epilogue (the loop's last barrier guarantees every wave is done reading the stages) -----
     static_assert(NW * kEpiWaveBytes(WTN) <= 2 * BUF, "epilogue stage does not fit the K-loop LDS");
-    epilogue_store<FM, FN>(acc, smem + wave * kEpiWaveBytes(WTN), g, est, lane);
+    epilogue_store<FM, FN, SPLIT>(acc, smem + wave * kEpiWaveBytes(WTN), g, est, lane);
 #endif
 }
 
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+template <int BM, int BN, int BK, int WGM, int WGN, bool SPLIT = false>
 int launch(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * BK * 2;
     static_assert(lds <= 65536, "tiles above 64 KiB of LDS need hipFuncSetAttribute");
@@ -209,7 +209,7 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     b.tiles_n = (a.N + BN - 1) / BN;
     const long long nblk = (long long)b.tiles_m * b.tiles_n;
     if (nblk > 0x7fffffffLL) return ASL_EINVAL;
-    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, BK, WGM, WGN>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), lds, stream, b);
+    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, BK, WGM, WGN, SPLIT>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), lds, stream, b);
     return (int)hipGetLastError();
 }
 
@@ -228,6 +228,13 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
                                     const float* bias, const void* res, void* y, asl_stream_t stream) {
     if (!p || !x || !w || !y) return ASL_EINVAL;
     if (p->variant < ASL_CONV_AUTO || p->variant > ASL_CONV_C64 || (p->out_s2d != 0 && p->out_s2d != 1)) return ASL_EINVAL;
+    if (p->split_out != 0 && p->split_out != 1) return ASL_EINVAL;
+    if (p->split_out) {
+        // split-precision output (and residual): bf16 only, lo halves 16-byte aligned behind the hi halves, both in bounds
+        if (p->out_f32 || p->res_f32 || p->out_s2d || p->out_lo < p->cout || (p->out_lo & 7)) return ASL_EINVAL;
+        if (res && (p->res_lo < p->cout || (p->res_lo & 7))) return ASL_EINVAL;
+        if (p->variant > ASL_CONV_GATHER) return ASL_ENOTSUP;               // only the gather-GEMM writes it
+    }
     if (p->nb <= 0 || p->od <= 0 || p->oh <= 0 || p->ow <= 0 || p->cout <= 0) return ASL_EINVAL;
     if (p->kd <= 0 || p->kh <= 0 || p->kw <= 0 || p->ck <= 0 || (p->ck & 31)) return ASL_EINVAL;
     if (p->tap_sd < 0 || p->tap_sh < 0 || p->tap_sw < 0) return ASL_EINVAL;
@@ -257,8 +264,8 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
         const long long last = (long long)(p->nb - 1) * p->out.sn + (long long)(p->oh >> 1) * p->out.sh +
                                (long long)(p->ow >> 1) * p->out.sw + 3LL * p->out.sd + p->out.off0 + p->cout;
         if (last > p->y_elems) return ASL_EINVAL;
-    } else if (geom_extent(p->out, p->nb, p->od, p->oh, p->ow) + p->cout > p->y_elems) return ASL_EINVAL;
-    if (res && geom_extent(p->res, p->nb, p->od, p->oh, p->ow) + p->cout > p->res_elems) return ASL_EINVAL;
+    } else if (geom_extent(p->out, p->nb, p->od, p->oh, p->ow) + (p->split_out ? p->out_lo : 0) + p->cout > p->y_elems) return ASL_EINVAL;
+    if (res && geom_extent(p->res, p->nb, p->od, p->oh, p->ow) + (p->split_out ? p->res_lo : 0) + p->cout > p->res_elems) return ASL_EINVAL;
     // one tile's rows must stay within a 2 GiB window of the input (32-bit DMA offsets)
     {
         const long long odhw = (long long)p->od * p->oh * p->ow;
@@ -282,8 +289,14 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
     a.x_bytes = 2 * p->x_elems; a.w_bytes = 2 * wk * p->w_rows;
     a.relu = p->relu; a.out_f32 = p->out_f32; a.res_f32 = p->res_f32;
     a.tiles_m = a.tiles_n = 0;
+    a.out_lo = p->out_lo; a.res_lo = p->res_lo;
 
     hipStream_t s = (hipStream_t)stream;
+    if (p->split_out) {                         // parity mode: one tile shape per K granule, split-precision epilogue
+        if (p->ck % 64 == 0) { a.ksteps_per_tap = p->ck / 64; return launch<128, 128, 64, 2, 4, true>(a, s); }
+        a.ksteps_per_tap = p->ck / 32;
+        return launch<128, 128, 32, 2, 4, true>(a, s);
+    }
     // 3x3 / stride 1 / pad 1 on a halo'd NHWC tensor with C % 64 == 0: the LDS-resident-patch kernel
     if (p->kd == 1 && p->kh == 3 && p->kw == 3 && p->od == 1 && (p->ck & 63) == 0 && !p->out_f32 && !p->res_f32 &&
         p->tap_sw == p->ck && p->in.sw == p->ck && p->in.sh == p->tap_sh && p->tap_sh % p->ck == 0 &&

@@ -26,6 +26,7 @@ struct GemmArgs {
     long long x_bytes, w_bytes;
     int relu, out_f32, res_f32;
     int tiles_m, tiles_n;
+    int out_lo, res_lo;          // split-precision output / residual (SPLIT instances): element offset of the lo half
 };
 
 }  // namespace asl_detail

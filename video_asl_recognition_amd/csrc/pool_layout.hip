@@ -531,6 +531,53 @@ extern "C" int asl_maxpool3d_ndhwc(const asl_pool3d_params* p, const void* x, vo
     return (int)hipGetLastError();
 }
 
+// nn.MaxPool2d(3, 2, 1) on a split-precision tensor (parity mode): [n][h+2*ih][w+2*ih][2c], channels [0, c) the hi halves
+// and [c, 2c) the lo halves of values >= 0.  A thread takes 8 channels of one output pixel: max over the window of hi + lo in
+// fp32 (the zero halo is neutral), written back as a hi / lo pair.
+__global__ __launch_bounds__(256) void maxpool3x3s2_split_kernel(const short* __restrict__ x, short* __restrict__ y, int n, int h,
+                                                                 int w, int c, int ih, int oh_) {
+    const int c8 = c >> 3, ohh = (h + 2 - 3) / 2 + 1, oww = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)n * ohh * oww * c8;
+    const int wp = w + 2 * ih, hp = h + 2 * ih, owp = oww + 2 * oh_, ohp = ohh + 2 * oh_;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % c8);
+        long long r = i / c8;
+        const int ox = (int)(r % oww); r /= oww;
+        const int oy = (int)(r % ohh);
+        const long long img = r / ohh;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = 0.f;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const long long px = (img * hp + (2 * oy - 1 + ky + ih)) * wp + (2 * ox - 1 + kx + ih);
+                const bf16x8 hv = *(const bf16x8*)(x + px * 2 * c + g * 8);
+                const bf16x8 lv = *(const bf16x8*)(x + px * 2 * c + c + g * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], bf16_to_f32(hv[e]) + bf16_to_f32(lv[e]));
+            }
+        bf16x8 ho, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ho[e] = f32_to_bf16(m[e]);
+            lo[e] = f32_to_bf16(m[e] - bf16_to_f32(ho[e]));
+        }
+        const long long opx = (img * ohp + oy + oh_) * owp + ox + oh_;
+        *(bf16x8*)(y + opx * 2 * c + g * 8) = ho;
+        *(bf16x8*)(y + opx * 2 * c + c + g * 8) = lo;
+    }
+}
+
+extern "C" int asl_maxpool3x3s2_split_nhwc(const void* x, int n, int h, int w, int c, int in_halo, void* y, int out_halo,
+                                           asl_stream_t stream) {
+    if (!x || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 7) || in_halo < 1 || out_halo < 0) return ASL_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return ASL_EINVAL;
+    const long long total = (long long)n * ((h - 1) / 2 + 1) * ((w - 1) / 2 + 1) * (c / 8);
+    hipLaunchKernelGGL(maxpool3x3s2_split_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const short*)x,
+                       (short*)y, n, h, w, c, in_halo, out_halo);
+    return (int)hipGetLastError();
+}
+
 extern "C" int asl_maxpool3x3s2_nhwc(const void* x, int n, int h, int w, int c, int in_halo, void* y, int out_halo,
                                      asl_stream_t stream) {
     asl_pool3d_params p;

@@ -76,7 +76,7 @@ class _BufPool:
 
 class AslClipModel:
     def __init__(self, spec, device: str = "cuda", frames_per_chunk: Optional[int] = None, seed: Optional[int] = None,
-                 streams: int = 2, s2d_entry: Optional[bool] = None):
+                 streams: int = 2, s2d_entry: Optional[bool] = None, parity_mode: Optional[bool] = None):
         self.spec: ModelSpec = SPECS[spec] if isinstance(spec, str) else spec
         if not torch.cuda.is_available():
             raise RuntimeError("AslClipModel needs an MI355X (no GPU visible); there is no CPU path")
@@ -101,6 +101,13 @@ class AslClipModel:
         # previous block's last kernel writes (asl_block_entry_s2_bf16).  Opt-in (argument, or ASL_S2D_ENTRY=1): measured
         # slower than the two gather-GEMM launches it replaces (254 / 188 / 145 us against 190 / 122 / 105 at 640 frames)
         self.s2d_entry = (os.environ.get("ASL_S2D_ENTRY", "0") == "1") if s2d_entry is None else bool(s2d_entry)
+        # Parity mode (argument, or ASL_PARITY_MODE=1; ResNet backbones): every activation travels as a bf16 pair hi + lo
+        # (~16 mantissa bits) instead of one bf16 value, every convolution reads both halves against weights duplicated
+        # along K, and accumulation, BatchNorm, residual and ReLU stay fp32 as always -- twice the arithmetic and traffic,
+        # for inputs whose conditioning makes single-bf16 activations miss the 1e-3 bar.  All convs on the gather-GEMM.
+        self.parity_mode = (os.environ.get("ASL_PARITY_MODE", "0") == "1") if parity_mode is None else bool(parity_mode)
+        if self.parity_mode and self.spec.backbone not in RESNET_LAYERS:
+            raise NotImplementedError("parity mode covers the ResNet backbones")
         self._w: Dict[str, PackedConv] = {}
         self._fc_w = self._fc_b = None
         self._temporal = None
@@ -129,14 +136,15 @@ class AslClipModel:
             s, b = bn_scale_bias(sd, "backbone.bn1", 1e-5, dev)
             w["stem"] = pack_stem(sd["backbone.conv1.weight"], dev, s, b)
             nconv = 2 if RESNET_LAYERS[spec.backbone][0] == "basic" else 3
+            split = self.parity_mode
             for prefix, cin, planes, stride, ds in resnet_blocks(spec.backbone):
                 for i in range(1, nconv + 1):
                     s, b = bn_scale_bias(sd, f"{prefix}.bn{i}", 1e-5, dev)
-                    w[f"{prefix}.conv{i}"] = pack_conv(sd[f"{prefix}.conv{i}.weight"], dev, scale=s, bias=b)
+                    w[f"{prefix}.conv{i}"] = pack_conv(sd[f"{prefix}.conv{i}.weight"], dev, scale=s, bias=b, split=split)
                 if ds:
                     s, b = bn_scale_bias(sd, f"{prefix}.downsample.1", 1e-5, dev)
-                    w[f"{prefix}.ds"] = pack_conv(sd[f"{prefix}.downsample.0.weight"], dev, scale=s, bias=b)
-                    if nconv == 2 and stride == 2 and cin % 32 == 0 and planes % 128 == 0:
+                    w[f"{prefix}.ds"] = pack_conv(sd[f"{prefix}.downsample.0.weight"], dev, scale=s, bias=b, split=split)
+                    if not split and nconv == 2 and stride == 2 and cin % 32 == 0 and planes % 128 == 0:
                         # the same two weight sets in MFMA-fragment order for the one-launch block entry
                         c1 = w[f"{prefix}.conv1"]
                         w[f"{prefix}.entry"] = pack_entry_conv(sd[f"{prefix}.conv1.weight"], dev, c1.scale, c1.bias)
@@ -174,18 +182,21 @@ class AslClipModel:
             ops.append(dict(op=L.make_op(kind, params, [t.data_ptr() if t is not None else None for t in ptrs], ints),
                             params=params, n_slot=n_slot, conv=conv, keep=(params, ptrs, keep)))
 
+        pm = self.parity_mode     # parity mode: Acts hold [hi | lo] halves (2 x the logical channels), gather-GEMM only
+
         def conv_op(pc: PackedConv, x: Act, y: Act, stride, pad, relu, res: Optional[Act] = None):
             kd, kh, kw = pc.k
             p = L.Conv2dParams(n=0, h=x.h, w=x.w, cin=x.c, in_halo=x.halo, cout=pc.cout, kh=kh, kw=kw,
                                stride=stride, pad=pad, out_halo=y.halo, out_ctot=y.c, out_coff=0,
                                res_halo=res.halo if res else 0, res_ctot=res.c if res else 0, res_coff=0,
-                               relu=int(relu), w_rows=pc.w_rows, variant=self.conv_variant, out_s2d=int(y.cells))
+                               relu=int(relu), w_rows=pc.w_rows, variant=L.CONV_GATHER if pm else self.conv_variant,
+                               out_s2d=int(y.cells), out_split=int(pm))
             add(L.OP_CONV2D, p, (x.t, pc.w, pc.scale, pc.bias, res.t if res else None, y.t), conv=True, keep=(x, y, res, pc))
 
         def stem_op(pc: PackedConv, x0: torch.Tensor, in_halo, y: Act, stride, pad, relu):
             kd, kh, kw = pc.k
             p = L.StemParams(n=0, h=S, w=S, in_halo=in_halo, cout=pc.cout, kh=kh, kw=kw, stride=stride, pad=pad,
-                             out_halo=y.halo, relu=int(relu), w_rows=pc.w_rows)
+                             out_halo=y.halo, relu=int(relu), w_rows=pc.w_rows, out_split=int(pm))
             add(L.OP_STEM_CONV, p, (x0, pc.w, pc.scale, pc.bias, y.t), conv=True, keep=(y, pc))
 
         if spec.backbone == "tiny":
@@ -198,8 +209,14 @@ class AslClipModel:
         else:
             in_halo = 3
             x0 = torch.zeros(nmax, S + 6, S + 6, 4, dtype=torch.bfloat16, device=dev)
-            x = pool.get(S // 4, S // 4, 64)
-            if not self.fused_stem:
+            cm = 2 if pm else 1                               # channel multiple of every activation buffer
+            x = pool.get(S // 4, S // 4, 64 * cm)
+            if pm:
+                a = pool.get(S // 2, S // 2, 128)
+                stem_op(self._w["stem"], x0, in_halo, a, 2, 3, True)
+                add(L.OP_MAXPOOL_SPLIT, None, (a.t, x.t), (0, a.h, a.w, 64, a.halo, x.halo), n_slot=0, keep=(a, x))
+                pool.put(a)
+            elif not self.fused_stem:
                 a = pool.get(S // 2, S // 2, 64)
                 stem_op(self._w["stem"], x0, in_halo, a, 2, 3, True)
                 add(L.OP_MAXPOOL, None, (a.t, x.t), (0, a.h, a.w, a.c, a.halo, x.halo), n_slot=0, keep=(a, x))
@@ -210,14 +227,14 @@ class AslClipModel:
                 add(L.OP_STEM_POOL, sp, (x0, pc.w, pc.scale, pc.bias, x.t), conv=True, keep=(x, pc))
             basic = RESNET_LAYERS[spec.backbone][0] == "basic"
             blocks = list(resnet_blocks(spec.backbone))
-            cells_ok = basic and self.s2d_entry and self.conv_variant in (0, L.CONV_PP)
+            cells_ok = basic and self.s2d_entry and self.conv_variant in (0, L.CONV_PP) and not pm
             for bi, (prefix, cin, planes, stride, ds) in enumerate(blocks):
                 oh, ow = x.h // stride, x.w // stride
                 w = self._w
                 # the next block is a stride-2 entry that can take its input as cells, and this block's last kernel can
                 # write them (the paired fused block; the 8-wave 3x3 kernel: 128 channels and up, whole 128-channel tiles)
                 nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
-                fused = basic and self.fuse_blocks and not ds and stride == 1 and cin == planes == 64
+                fused = basic and self.fuse_blocks and not ds and stride == 1 and cin == planes == 64 and not pm
                 y_cells = bool(cells_ok and nxt and (nxt[0] + ".entry") in w and oh % 2 == 0 and ow % 2 == 0 and
                                (fused or (planes >= 128 and planes % 128 == 0)))
                 if fused:
@@ -229,7 +246,7 @@ class AslClipModel:
                     add(L.OP_BASIC_BLOCK, bp, (x.t, c1.w, c1.scale, c1.bias, c2.w, c2.scale, c2.bias, y.t), conv=True,
                         keep=(x, y, c1, c2))
                 elif basic:
-                    t = pool.get(oh, ow, planes)
+                    t = pool.get(oh, ow, planes * cm)
                     idt = x
                     if x.cells:
                         # conv1 (3x3 / stride 2) and the downsample (1x1 / stride 2) from one launch over the cells
@@ -242,21 +259,21 @@ class AslClipModel:
                     else:
                         conv_op(w[prefix + ".conv1"], x, t, stride, 1, True)
                         if ds:
-                            idt = pool.get(oh, ow, planes)
+                            idt = pool.get(oh, ow, planes * cm)
                             conv_op(w[prefix + ".ds"], x, idt, stride, 0, False)
-                    y = pool.get(oh, ow, planes, cells=y_cells)
+                    y = pool.get(oh, ow, planes * cm, cells=y_cells)
                     conv_op(w[prefix + ".conv2"], t, y, 1, 1, True, res=idt)
                     pool.put(t)
                 else:
-                    t1 = pool.get(x.h, x.w, planes)
+                    t1 = pool.get(x.h, x.w, planes * cm)
                     conv_op(w[prefix + ".conv1"], x, t1, 1, 0, True)
-                    t2 = pool.get(oh, ow, planes)
+                    t2 = pool.get(oh, ow, planes * cm)
                     conv_op(w[prefix + ".conv2"], t1, t2, stride, 1, True)
                     idt = x
                     if ds:
-                        idt = pool.get(oh, ow, planes * 4)
+                        idt = pool.get(oh, ow, planes * 4 * cm)
                         conv_op(w[prefix + ".ds"], x, idt, stride, 0, False)
-                    y = pool.get(oh, ow, planes * 4)
+                    y = pool.get(oh, ow, planes * 4 * cm)
                     conv_op(w[prefix + ".conv3"], t2, y, 1, 0, True, res=idt)
                     pool.put(t1)
                     pool.put(t2)
@@ -305,7 +322,9 @@ class AslClipModel:
         asl_run_ops call, op by op across the group, so the host pays one foreign call per group and the
         second stream starts a launch after the first."""
         F = self.spec.feat_dim
-        feats = torch.empty(n_total, F, dtype=torch.float32, device=self.device)
+        pm = self.parity_mode
+        Fp = 2 * F if pm else F        # parity mode: means of the hi and the lo halves side by side, folded below
+        feats = torch.empty(n_total, Fp, dtype=torch.float32, device=self.device)
         # bf16 copy of the features = GEMM operand of the temporal encoder; the two-stream model appends
         # the keypoint-MLP output to each row, so the row pitch may exceed F
         # and the BiLSTM takes split-precision features (hi | lo halves) for its input projection
@@ -341,13 +360,20 @@ class AslClipModel:
                 for k, slot in n_slots[j]:
                     arr[k].i[slot] = n
                 avg = arr[g + nops * g + j]
-                avg.ptr[1] = fbase + c0 * F * 4
-                avg.ptr[2] = (bbase + c0 * ld_b * 2) if feats_b is not None else None
+                avg.ptr[1] = fbase + c0 * Fp * 4
+                avg.ptr[2] = (bbase + c0 * ld_b * 2) if (feats_b is not None and not pm) else None
                 avg.i[5], avg.i[6] = ld_b, lo_off
             L.run_ops(arr, len(arr), sarr, nstreams, "backbone")
         if nstreams > 1:
             for s_ in side:
                 main.wait_stream(s_)
+        if pm:
+            feats = feats[:, :F] + feats[:, F:]
+            if feats_b is not None:
+                hi = feats.to(torch.bfloat16)
+                feats_b[:, :F] = hi
+                if lo_off:
+                    feats_b[:, lo_off:lo_off + F] = (feats - hi.float()).to(torch.bfloat16)
         return feats, feats_b
 
     def _side_streams(self, n):

@@ -38,18 +38,22 @@ def bn_scale_bias(sd, prefix: str, eps: float, device):
     return scale.contiguous().to(device), bias.contiguous().to(device)
 
 
-def pack_conv(w: torch.Tensor, device, cin_phys: Optional[int] = None, scale=None, bias=None) -> PackedConv:
-    """[cout, cin, (kd,) kh, kw] -> bf16 [w_rows][taps * cin_phys], tap-major, channels innermost."""
+def pack_conv(w: torch.Tensor, device, cin_phys: Optional[int] = None, scale=None, bias=None, split: bool = False) -> PackedConv:
+    """[cout, cin, (kd,) kh, kw] -> bf16 [w_rows][taps * cin_phys], tap-major, channels innermost.
+    split=True (parity mode): the input tensor carries [hi | lo] halves of every channel (2 * cin_phys channels per
+    pixel), so each tap's weights are written twice, once against each half."""
     w = w.to(torch.float32)
     if w.dim() == 4:
         w = w[:, :, None]                       # kd = 1
     cout, cin, kd, kh, kw = w.shape
     cin_phys = cin_phys or _round_up(cin, 32)
     w_rows = _round_up(cout, 128)
-    p = torch.zeros(w_rows, kd, kh, kw, cin_phys, dtype=torch.float32)
-    p[:cout, :, :, :, :cin] = w.permute(0, 2, 3, 4, 1)
-    p = p.reshape(w_rows, kd * kh * kw * cin_phys).to(torch.bfloat16).contiguous().to(device)
-    return PackedConv(p, scale, bias, cout, cin_phys, (kd, kh, kw), w_rows)
+    reps = 2 if split else 1
+    p = torch.zeros(w_rows, kd, kh, kw, reps * cin_phys, dtype=torch.float32)
+    for r in range(reps):
+        p[:cout, :, :, :, r * cin_phys:r * cin_phys + cin] = w.permute(0, 2, 3, 4, 1)
+    p = p.reshape(w_rows, kd * kh * kw * reps * cin_phys).to(torch.bfloat16).contiguous().to(device)
+    return PackedConv(p, scale, bias, cout, reps * cin_phys, (kd, kh, kw), w_rows)
 
 
 def pack_stem(w: torch.Tensor, device, scale=None, bias=None) -> PackedConv:
