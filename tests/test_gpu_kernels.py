@@ -513,6 +513,46 @@ def test_stem_conv_and_pack_clips(gpu):
     _assert_bf16_close(_unhalo(yd, 1), ref)
 
 
+# Stem conv + BatchNorm + ReLU + 3x3/2 max-pool in one launch: the pooled output must be the max-pool of the bf16-rounded
+# stem activation (rounding commutes with max).  Sizes: the configs' 224, one row segment (PH < 16), a strip count that
+# is not a multiple of the four waves (PW = 30: 5 strips), a last strip narrower than 7 pooled columns, H != W, and enough
+# frames that workgroups walk several tasks.
+@pytest.mark.parametrize("n,h,w,out_halo", [(2, 224, 224, 1), (3, 64, 64, 1), (1, 36, 36, 0), (2, 120, 120, 1),
+                                            (5, 40, 72, 2), (70, 64, 64, 1)])
+def test_stem_pool_fused(gpu, n, h, w, out_halo):
+    from video_asl_recognition_amd import _lib as L
+    from video_asl_recognition_amd.packing import pack_stem
+    g = torch.Generator().manual_seed(h * 3 + w)
+    clips = _bf16(torch.randn(n, 3, h, w, generator=g))
+    wt = _bf16(torch.randn(64, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5)
+    # BatchNorm scales of both signs and an exact zero: the kernel pools before it applies BatchNorm, which is only the
+    # same thing because it turns every channel into one with a non-negative scale first
+    scale = torch.empty(64).uniform_(0.5, 1.5, generator=g) * (torch.rand(64, generator=g) < 0.6).float().mul(2).sub(1)
+    scale[5] = 0.0
+    bias = torch.empty(64).normal_(0, 0.1, generator=g)
+    stem = F.relu(F.conv2d(clips, wt, None, 2, 3) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    x0 = F.pad(torch.cat([clips, torch.zeros(n, 1, h, w)], 1).permute(0, 2, 3, 1), (0, 0, 3, 3, 3, 3))
+    x0 = x0.to(torch.bfloat16).contiguous().cuda()
+    pc = pack_stem(wt, "cuda", scale.cuda(), bias.cuda())
+    oh_ = out_halo
+    yd = torch.full((n, h // 4 + 2 * oh_, w // 4 + 2 * oh_, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    p = L.StemPoolParams(n=n, h=h, w=w, cout=64, out_halo=oh_, w_rows=pc.w_rows)
+    L.check(L.lib.asl_stem_pool_bf16(C.byref(p), _p(x0), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(yd), None))
+    torch.cuda.synchronize()
+    got = _unhalo(yd, oh_)
+    # the unfused pair of kernels gives the reference bit pattern: same MFMA K order, then an exact max
+    sd = torch.zeros(n, h // 2 + 2, w // 2 + 2, 64, dtype=torch.bfloat16, device="cuda")
+    sp = L.StemParams(n=n, h=h, w=w, in_halo=3, cout=64, kh=7, kw=7, stride=2, pad=3, out_halo=1, relu=1, w_rows=pc.w_rows)
+    L.check(L.lib.asl_stem_conv_bf16(C.byref(sp), _p(x0), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(sd), None))
+    torch.cuda.synchronize()
+    want = F.max_pool2d(_unhalo(sd, 1), 3, 2, 1)
+    _assert_bf16_close(got, F.max_pool2d(stem, 3, 2, 1))
+    frac = float((got != want).float().mean())
+    assert frac < 1e-3, f"{frac:.2e} of the pooled values differ from maxpool(stem kernel output)"
+    if oh_:
+        assert (yd[:, :oh_].float() == 7).all() and (yd[:, :, -oh_:].float() == 7).all(), "halo was written"
+
+
 @pytest.mark.parametrize("s,halo", [(8, 0), (8, 1), (12, 2), (64, 3), (224, 3), (112, 1), (6, 3), (20, 5)])
 def test_pack_clips_bf16_layout_exact(gpu, s, halo):
     """bf16 clips -> packed 4-channel halo'd image, bit for bit, halo cells written as zeros (the destination is

@@ -20,6 +20,9 @@
 // ...; the next tile's patch is fetched (LDS-DMA, second patch buffer) while the MFMAs run.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "asl_hip.h"
 #include "common.h"
@@ -209,6 +212,291 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolArgs a)
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Column-strip form of the same fusion (the default).  The tile kernel above recomputes one conv row in
+// five (every wave needs the row above its first pooled row) and fetches a 39-row patch per 32 conv rows.
+// Here a WAVE is the unit: it owns a strip of 16 conv columns (7 pooled columns) and walks it top to bottom,
+// one conv row per step, so every conv row is computed once; the vertical 3-max is carried in registers from
+// row to row (pooled row py = conv rows 2py-1, 2py, 2py+1: the last of them also opens pooled row py+1).
+// Input rows stream through a private LDS ring of 16 row pairs (1 KiB slots: 2 rows x 320 B + padding) per wave,
+// one LDS-DMA instruction per step, issued kDist steps ahead and retired by counted s_waitcnt -- the waves of a
+// workgroup share nothing, so the kernel has no barrier at all.  A task is (image, half of the pooled rows,
+// strip); the four waves of a workgroup take four neighbouring strips, whose column overlap (40 packed pixels
+// fetched per 28 new) then hits in the CU's vector cache.
+//
+// Vector work per conv row is what bounds this kernel next to its 28 MFMAs, so it is cut to the minimum:
+//  * BatchNorm runs on POOLED values only.  s * a + b is monotonic in a once s >= 0, and a channel with s < 0 is
+//    turned into one with s > 0 by negating its weight row (exact in bf16 and through the fp32 accumulation), done
+//    on the fragments as they are loaded; then max commutes with BatchNorm bit for bit.
+//  * Conv pixels outside the image are set to -inf once per pooled row (columns) or skipped (row -1).
+//  * Weight rows are read in a permuted order so that a lane ends up with 16 consecutive output channels and
+//    stores 32 B per pooled pixel straight from registers, through a buffer descriptor (idle lanes need no branch).
+//  * The next row's first six fragments are read before the current row's MFMAs are issued.
+[[maybe_unused]] constexpr int kSlots = 16;               // ring slots (row pairs) per wave
+[[maybe_unused]] constexpr int kDist = 8;                 // DMA prefetch distance in conv rows (even); 4 + kDist <= kSlots
+[[maybe_unused]] constexpr int kSlot = 1024;              // ring slot: one row pair (640 B) + the idle lanes' zeros
+[[maybe_unused]] constexpr int kRingBytes = kSlots * kSlot;
+static_assert(kDist % 2 == 0 && 4 + kDist <= kSlots, "prefetch distance");
+
+struct StemStripArgs {
+    const char* x;       // packed [n][H+6][W+6][4] bf16
+    const char* w;       // [128][224] bf16 (pack_stem layout)
+    const float* scale;
+    const float* bias;
+    char* y;             // [n][PH+2*oh][PW+2*oh][64] bf16
+    int n, H, W, CH, CW, PH, PW, out_halo;
+    int strips, strip_groups, segs, seg_rows;   // strips of 7 pooled columns in groups of 4; row segments
+    long long x_bytes;
+    int ngroups;         // n * segs * strip_groups workgroup tasks
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Horizontal 3-max (lane i <- max of lanes i, i+1, i+2 of its 16-lane row) of eight values in one block: the two
+// wait states a DPP operand needs after a vector write are paid once per block, not per value.  Lanes past the row's
+// end read 0; they feed no stored pixel.
+__device__ __forceinline__ void row_max3_x8(const float (&v)[8], float (&m)[8]) {
+#define D1(i, j) "v_max_f32_dpp %" #i ", %" #j ", %" #j " row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define D2(i, j) "v_max_f32_dpp %" #i ", %" #j ", %" #i " row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm("s_nop 1\n\t" D1(0, 8) D1(1, 9) D1(2, 10) D1(3, 11) D1(4, 12) D1(5, 13) D1(6, 14) D1(7, 15)
+        D2(0, 8) D2(1, 9) D2(2, 10) D2(3, 11) D2(4, 12) D2(5, 13) D2(6, 14) D2(7, 15)
+        : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(m[4]), "=&v"(m[5]), "=&v"(m[6]), "=&v"(m[7])
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+#undef D1
+#undef D2
+}
+
+template <class T, int kOff>
+__device__ __forceinline__ T lds_read(unsigned ad) {
+    T v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(ad), "n"(kOff) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void stem_strip_kernel(const StemStripArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) char lds[4 * kRingBytes];
+    __shared__ __attribute__((aligned(16))) float bnt[128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int Wp = a.W + 6;
+    char* const ring = lds + wave * kRingBytes;
+    const unsigned ring_ad = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
+    constexpr float kNegInf = -__builtin_inff();
+
+    // ---- weights -> registers.  Fragment j, row rho holds channel (rho >> 2) * 16 + j * 4 + (rho & 3), so that the
+    // lane's 16 results (j, e) are channels fq * 16 + j * 4 + e: 16 consecutive ones.  Rows of channels with a
+    // negative BatchNorm scale are negated (sign bit of each bf16), and |scale| is used below.
+    bf16x8 wf[4][7];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = (fr >> 2) * 16 + j * 4 + (fr & 3);
+        const int flip = (a.scale && a.scale[ch] < 0.f) ? (int)0x80008000 : 0;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            i32x4 t = *(const i32x4*)(a.w + (ch * 224 + r * 32 + fq * 8) * 2);
+            t ^= flip;
+            wf[j][r] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
+    // |scale| and bias are needed once per pooled row only: they wait in LDS (a lane reads its 16 channels from there)
+    // and leave the registers to the fragments
+    if (tid < 64) {
+        bnt[tid] = a.scale ? __builtin_fabsf(a.scale[tid]) : 1.f;
+        bnt[64 + tid] = a.bias ? a.bias[tid] : 0.f;
+    }
+    __syncthreads();
+    const unsigned bn_ad = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)(char*)bnt + fq * 64;
+    const int owp = a.PW + 2 * a.out_halo, ohp = a.PH + 2 * a.out_halo;
+    // lane's place in a DMA instruction: rows 0 / 1 of the pair, 16-byte chunk 0..19; lanes 40..63 stay out of range
+    // (the DMA then writes zeros into the slot's padding) so the instruction needs no exec mask
+    const int drow = lane >= 20 ? 1 : 0, dch = lane - 20 * drow;
+    const bool dma_lane = lane < 40;
+    const unsigned rd = ring_ad + (2 * fr + 2 * fq) * 8;  // LDS address of the lane's fragment in slot 0, row 0
+    constexpr unsigned kOob = 0x80000000u;
+
+    for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
+        const int per_img = a.segs * a.strip_groups;
+        const int img = grp / per_img, rem = grp - img * per_img;
+        const int seg = rem / a.strip_groups, sg = rem - seg * a.strip_groups;
+        const int strip = sg * 4 + wave;
+        if (strip >= a.strips) continue;                  // (wave-uniform: the waves share no barrier)
+        const int py0 = seg * a.seg_rows;
+        const int npy = (py0 + a.seg_rows <= a.PH ? a.seg_rows : a.PH - py0);     // pooled rows of this task
+        const int cy0 = 2 * py0 - 1, cx0 = 14 * strip - 1;                        // first conv row / column (may be -1)
+        const int last_pair = 2 * npy + 3;                // conv row 2 * npy (the last) reads pairs up to this one
+        // Row pair k = halo'd input rows 2 * (cy0 + k), +1; columns from halo'd pixel 2 * cx0.  Descriptor rebased to
+        // the task so lane offsets stay small; what falls before the tensor (cy0 = -1, cx0 = -1 on the first image)
+        // reads as zero, and those conv pixels are masked anyway.
+        const long long org = ((long long)img * (a.H + 6) * Wp + (long long)(2 * cy0) * Wp + 2 * cx0) * 8;
+        const long long shift = org > 0 ? org : 0;        // org is a multiple of 16 (Wp even, 2 * cx0 even)
+        const long long rem_b = a.x_bytes - shift;
+        const unsigned rec = (unsigned)(rem_b > 0x7fffffffLL ? 0x7fffffffLL : rem_b);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + shift), 0, rec, 0x00020000);
+        const int rel = (int)(org - shift);               // 0, or negative on the first rows of the first image
+        const int lane_src = dma_lane ? rel + drow * Wp * 8 + dch * 16 : -1;
+        auto dma_pair = [&](int k) {
+            // pairs past the task's last one move no data (out-of-range offset: the DMA writes zeros), so the count
+            // of instructions in flight is the same on every step
+            const int off = lane_src + k * (2 * Wp * 8);
+            const unsigned vo = (k <= last_pair && lane_src != -1 && off >= 0) ? (unsigned)off : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ring + (k & (kSlots - 1)) * kSlot),
+                                                     16, vo, 0, 0, 0);
+            asm volatile("" ::: "memory");                // the counted waits need DMAs and stores in program order
+        };
+        // output through a descriptor on this image: lanes that store nothing get an out-of-range offset
+        const long long img_bytes = (long long)ohp * owp * 128;
+        __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + img * img_bytes), 0, (unsigned)img_bytes,
+                                                                      0x00020000);
+        const int px = 7 * strip + (fr >> 1);
+        const bool store = !(fr & 1) && fr < 14 && px < a.PW;
+        const unsigned out0 = store ? (unsigned)((((py0 + a.out_halo) * owp + px + a.out_halo) * 64 + fq * 16) * 2) : kOob;
+        const int cx = cx0 + fr;
+        const bool col_in = cx >= 0 && cx < a.CW;
+        const bool edge_cols = cx0 < 0 || cx0 + 14 >= a.CW;      // lanes 0..14 feed pooled pixels; lane 15 none
+
+        // Fragment r of the conv row in ring position C (= step & (kSlots - 1)): input row 2C + r = pair C + (r >> 1), row
+        // r & 1 of it.  The reads are inline assembly on purpose: the compiler orders a visible LDS read behind EVERY
+        // LDS-DMA in flight (s_waitcnt vmcnt(0)), which would undo the prefetch distance.
+        auto read6 = [&](auto Cc, bf16x8 (&x)[7]) {
+            constexpr int C = decltype(Cc)::value;
+            x[0] = lds_read<bf16x8, ((C + 0) & (kSlots - 1)) * kSlot>(rd);
+            x[1] = lds_read<bf16x8, ((C + 0) & (kSlots - 1)) * kSlot + 320>(rd);
+            x[2] = lds_read<bf16x8, ((C + 1) & (kSlots - 1)) * kSlot>(rd);
+            x[3] = lds_read<bf16x8, ((C + 1) & (kSlots - 1)) * kSlot + 320>(rd);
+            x[4] = lds_read<bf16x8, ((C + 2) & (kSlots - 1)) * kSlot>(rd);
+            x[5] = lds_read<bf16x8, ((C + 2) & (kSlots - 1)) * kSlot + 320>(rd);
+        };
+        auto read_last = [&](auto Cc, bf16x8 (&x)[7]) {
+            constexpr int C = decltype(Cc)::value;
+            x[6] = lds_read<bf16x8, ((C + 3) & (kSlots - 1)) * kSlot>(rd);
+        };
+        // the seven fragments are in their registers once at most the six reads issued since are still out
+        auto frags_ready = [&](bf16x8 (&x)[7]) {
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]));
+        };
+        auto mfma_row = [&](const bf16x8 (&xf)[7], f32x4 (&acc)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][r], xf[r], acc[j], 0, 0, 0);
+        };
+        // pooled row from the vertical maxima of raw accumulators: mask columns, horizontal 3-max, BatchNorm, ReLU, store
+        auto emit = [&](int p, const f32x4 (&m)[4]) {
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+            i32x4 o[2];
+            f32x4 bn[8];                                   // |scale| of the lane's 16 channels, then their biases
+            bn[0] = lds_read<f32x4, 0>(bn_ad);   bn[1] = lds_read<f32x4, 16>(bn_ad);
+            bn[2] = lds_read<f32x4, 32>(bn_ad);  bn[3] = lds_read<f32x4, 48>(bn_ad);
+            bn[4] = lds_read<f32x4, 256>(bn_ad); bn[5] = lds_read<f32x4, 272>(bn_ad);
+            bn[6] = lds_read<f32x4, 288>(bn_ad); bn[7] = lds_read<f32x4, 304>(bn_ad);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]), "+v"(bn[4]), "+v"(bn[5]),
+                         "+v"(bn[6]), "+v"(bn[7]));
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float v[8], h[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = m[half * 2 + (i >> 2)][i & 3];
+                if (edge_cols) {                           // (wave-uniform) columns outside the image count for nothing
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = col_in ? v[i] : kNegInf;
+                }
+                row_max3_x8(v, h);
+                const f32x4 s0 = bn[half * 2], s1 = bn[half * 2 + 1], b0 = bn[4 + half * 2], b1 = bn[4 + half * 2 + 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q = 2 * i;                   // values q, q + 1 -> one packed pair
+                    const float t0 = h[q] * (q < 4 ? s0[q & 3] : s1[q & 3]) + (q < 4 ? b0[q & 3] : b1[q & 3]);
+                    const float t1 = h[q + 1] * (q < 4 ? s0[(q + 1) & 3] : s1[(q + 1) & 3]) + (q < 4 ? b0[(q + 1) & 3] : b1[(q + 1) & 3]);
+                    unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{t0, t1}, bf16x2_t));
+                    // as 16-bit integers, negative bf16 values are negative: ReLU of the rounded pair in one instruction
+                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk) : "v"(pk));
+                    o[half][i] = (int)pk;
+                }
+            }
+            const unsigned off = out0 == kOob ? kOob : out0 + (unsigned)(p * owp * 128);
+            __builtin_amdgcn_raw_buffer_store_b128(o[0], ys, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o[1], ys, off == kOob ? kOob : off + 16, 0, 0);
+            asm volatile("" ::: "memory");
+        };
+
+        // One step = one conv row c: issue the next row's first six fragment reads, multiply this row, then -- pair
+        // c + 4 (the next row's last fragment) being the only thing the next row still waits for -- retire its DMA,
+        // issue the DMA kDist pairs further on, and read that last fragment.  Vector-memory operations complete in
+        // order, so "pair c + 4 has landed" = at most kWait operations issued after its DMA are still out: the kDist - 1
+        // DMAs of the steps since and two stores per pooled row closed in those kDist steps (every other one).  The
+        // prologue issues out-of-range (dropped) stores where the steps before the first would have stored, so the count
+        // holds from step 0 on.
+        bf16x8 xa[7], xb[7];
+        f32x4 ve[4], vo_[4], m[4];
+#define STEM_STEP(CM, c, CUR, NXT, ACC)                            \
+    {                                                              \
+        read6(std::integral_constant<int, ((CM) + 1) & (kSlots - 1)>{}, NXT);     \
+        frags_ready(CUR);                                          \
+        mfma_row(CUR, ACC);                                        \
+        wait_vm<kWait>();                                          \
+        dma_pair((c) + 4 + kDist);                                 \
+        read_last(std::integral_constant<int, ((CM) + 1) & (kSlots - 1)>{}, NXT); \
+    }
+        // the previous task's fragment reads are behind us (their MFMAs were issued); its trailing DMAs are older than
+        // the ones issued now and land first
+        constexpr int kWait = 2 * kDist - 1;
+        auto placeholder_stores = [&]() {
+            __builtin_amdgcn_raw_buffer_store_b128(i32x4{0, 0, 0, 0}, ys, kOob, 0, 0);
+            asm volatile("" ::: "memory");                // (two instructions: identical neighbours would be merged)
+            __builtin_amdgcn_raw_buffer_store_b128(i32x4{0, 0, 0, 0}, ys, kOob + 16, 0, 0);
+            asm volatile("" ::: "memory");
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dma_pair(k);
+#pragma unroll
+        for (int k = 0; k < kDist; ++k) {                 // what steps -kDist .. -1 would have issued
+            dma_pair(4 + k);
+            if (!(k & 1)) placeholder_stores();
+        }
+        wait_vm<2 * kDist>();                             // pairs 0..3
+        read6(std::integral_constant<int, 0>{}, xa);
+        read_last(std::integral_constant<int, 0>{}, xa);
+        // conv row 0 = row 2 * py0 - 1: outside the image for the first segment
+        STEM_STEP(0, 0, xa, xb, ve)
+        placeholder_stores();
+        if (cy0 < 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ve[j] = f32x4{kNegInf, kNegInf, kNegInf, kNegInf};
+        }
+        // pooled row p: conv rows 2p + 1 (odd step) and 2p + 2 (even step, which closes it).  kSlots / 2 pooled rows per
+        // trip keep the ring slot of every read a compile-time constant.
+#define STEM_POOLED(U)                                             \
+    {                                                              \
+        const int p = p0 + (U);                                    \
+        if (p >= npy) break;                                       \
+        const int c = 2 * p + 1;                                   \
+        STEM_STEP(2 * (U) + 1, c, xb, xa, vo_)                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)              \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) m[j][e] = fmaxf(ve[j][e], vo_[j][e]); \
+        STEM_STEP(2 * (U) + 2, c + 1, xa, xb, ve)                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)              \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) m[j][e] = fmaxf(m[j][e], ve[j][e]); \
+        emit(p, m);                                                \
+    }
+        static_assert(kSlots == 16, "eight pooled rows per trip below");
+        for (int p0 = 0; p0 < npy; p0 += kSlots / 2) {
+            STEM_POOLED(0) STEM_POOLED(1) STEM_POOLED(2) STEM_POOLED(3)
+            STEM_POOLED(4) STEM_POOLED(5) STEM_POOLED(6) STEM_POOLED(7)
+        }
+#undef STEM_POOLED
+#undef STEM_STEP
+    }
+#endif
+}
+
 }  // namespace asl_detail
 using namespace asl_detail;
 
@@ -220,6 +508,26 @@ extern "C" int asl_stem_pool_bf16(const asl_stem_pool_params* p, const void* x, 
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)scale & 15) ||
         ((uintptr_t)bias & 15))
         return ASL_EINVAL;
+    static const bool use_tiles = getenv("ASL_STEM_TILES") && atoi(getenv("ASL_STEM_TILES"));   // A/B: the tile kernel
+    if (!use_tiles) {
+        StemStripArgs s;
+        s.x = (const char*)x; s.w = (const char*)w; s.scale = scale; s.bias = bias; s.y = (char*)y;
+        s.n = p->n; s.H = p->h; s.W = p->w; s.CH = p->h / 2; s.CW = p->w / 2; s.PH = p->h / 4; s.PW = p->w / 4;
+        s.out_halo = p->out_halo;
+        s.strips = (s.PW + 6) / 7;
+        s.strip_groups = (s.strips + 3) / 4;
+        s.segs = s.PH >= 16 ? 2 : 1;                       // two tasks per strip: 10 240 of them at 640 frames of 224 x 224
+        s.seg_rows = (s.PH + s.segs - 1) / s.segs;
+        s.x_bytes = (long long)p->n * (p->h + 6) * (p->w + 6) * 8;
+        const long long groups = (long long)p->n * s.segs * s.strip_groups;
+        if (groups > 0x7fffffffLL) return ASL_EINVAL;
+        if ((long long)(s.PH + 2 * s.out_halo) * (s.PW + 2 * s.out_halo) * 128 > 0x7fffffffLL) return ASL_EINVAL;
+        s.ngroups = (int)groups;
+        const long long slots = 2LL * device_cus();
+        hipLaunchKernelGGL(stem_strip_kernel, dim3((unsigned)(groups < slots ? groups : slots)), dim3(256), 0,
+                           (hipStream_t)stream, s);
+        return (int)hipGetLastError();
+    }
     StemPoolArgs a;
     a.x = (const char*)x; a.w = (const char*)w; a.scale = scale; a.bias = bias; a.y = (char*)y;
     a.n = p->n; a.H = p->h; a.W = p->w; a.CH = p->h / 2; a.CW = p->w / 2; a.PH = p->h / 4; a.PW = p->w / 4;
