@@ -217,11 +217,15 @@ int asl_stem_conv_bf16(const asl_stem_params* p, const void* x, const void* w,
  * BatchNorm2d(eval) + ReLU + nn.MaxPool2d(3, 2, 1) in one kernel (the 112x112x64 stem activation
  * never reaches HBM).  x: packed [n][h+6][w+6][4] bf16 (asl_pack_clips / asl_preprocess_u8 with halo
  * 3); w packed as for asl_stem_conv_bf16 ([w_rows][7*32]); y: [n][h/4+2*out_halo][w/4+2*out_halo][64].
- * h, w multiples of 4; cout must be 64 (ASL_ENOTSUP otherwise). */
+ * h, w multiples of 4; cout must be 64 (ASL_ENOTSUP otherwise).
+ * planar = 1: x is the clip tensor itself, bf16 [n][3][h][w] (no packed copy, no halo: the kernel pads), and w is
+ * [w_rows][6*32]: K ordered (filter row, channel, 8 taps starting one pixel left of the filter, that first tap zero),
+ * 21 groups of 8 and 3 zero groups. */
 typedef struct asl_stem_pool_params {
     int32_t n, h, w;
     int32_t cout, out_halo;
     int32_t w_rows;
+    int32_t planar;
 } asl_stem_pool_params;
 
 int asl_stem_pool_bf16(const asl_stem_pool_params* p, const void* x, const void* w,
@@ -394,6 +398,7 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
  * the params structs it points to and the streams array are read during the call only.
  *
  *   kind                 params                  ptr[]                                   i[] / f[]
+ *   ASL_OP_NOP (0)       NULL                    -                                       (nothing is launched)
  *   ASL_OP_CONV2D        asl_conv2d_params*      x, w, scale, bias, res, y
  *   ASL_OP_STEM_CONV     asl_stem_params*        x, w, scale, bias, y
  *   ASL_OP_STEM_POOL     asl_stem_pool_params*   x, w, scale, bias, y
@@ -414,7 +419,7 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
  * before it have been issued, ops after it have not.  ASL_EINVAL for an unknown kind, a stream index outside
  * [0, nstreams) or a missing params struct. */
 enum {
-    ASL_OP_CONV2D = 1, ASL_OP_STEM_CONV = 2, ASL_OP_STEM_POOL = 3, ASL_OP_CONV3D = 4, ASL_OP_LINEAR = 5,
+    ASL_OP_NOP = 0, ASL_OP_CONV2D = 1, ASL_OP_STEM_CONV = 2, ASL_OP_STEM_POOL = 3, ASL_OP_CONV3D = 4, ASL_OP_LINEAR = 5,
     ASL_OP_MAXPOOL3D = 6, ASL_OP_MAXPOOL = 7, ASL_OP_AVGPOOL = 8, ASL_OP_PACK_CLIPS = 9, ASL_OP_PREPROCESS = 10,
     ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12, ASL_OP_BASIC_BLOCK = 13, ASL_OP_BLOCK_ENTRY = 14, ASL_OP_MAXPOOL_SPLIT = 15
 };

@@ -517,11 +517,14 @@ def test_stem_conv_and_pack_clips(gpu):
 # stem activation (rounding commutes with max).  Sizes: the configs' 224, one row segment (PH < 16), a strip count that
 # is not a multiple of the four waves (PW = 30: 5 strips), a last strip narrower than 7 pooled columns, H != W, and enough
 # frames that workgroups walk several tasks.
+@pytest.mark.parametrize("planar", [0, 1], ids=["packed", "planar"])
 @pytest.mark.parametrize("n,h,w,out_halo", [(2, 224, 224, 1), (3, 64, 64, 1), (1, 36, 36, 0), (2, 120, 120, 1),
                                             (5, 40, 72, 2), (70, 64, 64, 1)])
-def test_stem_pool_fused(gpu, n, h, w, out_halo):
+def test_stem_pool_fused(gpu, n, h, w, out_halo, planar):
+    """planar: the same launch on the bf16 clip tensor [n][3][h][w] itself (zero padding applied by the kernel) with the
+    weights in the (filter row, channel, tap) K order"""
     from video_asl_recognition_amd import _lib as L
-    from video_asl_recognition_amd.packing import pack_stem
+    from video_asl_recognition_amd.packing import pack_stem, pack_stem_planar
     g = torch.Generator().manual_seed(h * 3 + w)
     clips = _bf16(torch.randn(n, 3, h, w, generator=g))
     wt = _bf16(torch.randn(64, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5)
@@ -536,8 +539,13 @@ def test_stem_pool_fused(gpu, n, h, w, out_halo):
     pc = pack_stem(wt, "cuda", scale.cuda(), bias.cuda())
     oh_ = out_halo
     yd = torch.full((n, h // 4 + 2 * oh_, w // 4 + 2 * oh_, 64), 7.0, dtype=torch.bfloat16, device="cuda")
-    p = L.StemPoolParams(n=n, h=h, w=w, cout=64, out_halo=oh_, w_rows=pc.w_rows)
-    L.check(L.lib.asl_stem_pool_bf16(C.byref(p), _p(x0), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(yd), None))
+    p = L.StemPoolParams(n=n, h=h, w=w, cout=64, out_halo=oh_, w_rows=pc.w_rows, planar=planar)
+    if planar:
+        pp = pack_stem_planar(wt, "cuda", scale.cuda(), bias.cuda())
+        xin = clips.to(torch.bfloat16).contiguous().cuda()
+        L.check(L.lib.asl_stem_pool_bf16(C.byref(p), _p(xin), _p(pp.w), _p(pp.scale), _p(pp.bias), _p(yd), None))
+    else:
+        L.check(L.lib.asl_stem_pool_bf16(C.byref(p), _p(x0), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(yd), None))
     torch.cuda.synchronize()
     got = _unhalo(yd, oh_)
     # the unfused pair of kernels gives the reference bit pattern: same MFMA K order, then an exact max
@@ -548,7 +556,9 @@ def test_stem_pool_fused(gpu, n, h, w, out_halo):
     want = F.max_pool2d(_unhalo(sd, 1), 3, 2, 1)
     _assert_bf16_close(got, F.max_pool2d(stem, 3, 2, 1))
     frac = float((got != want).float().mean())
-    assert frac < 1e-3, f"{frac:.2e} of the pooled values differ from maxpool(stem kernel output)"
+    # the packed form accumulates in the stem kernel's K order (bit-identical but for ties); the planar form in another
+    # one, so roundings to bf16 flip for a few values in a hundred
+    assert frac < (5e-2 if planar else 1e-3), f"{frac:.2e} of the pooled values differ from maxpool(stem kernel output)"
     if oh_:
         assert (yd[:, :oh_].float() == 7).all() and (yd[:, :, -oh_:].float() == 7).all(), "halo was written"
 

@@ -64,11 +64,17 @@ def main():
     total = 0.0
     print(f"# {name}: {B} clips x {T} frames per chunk, one launch at a time, {reps} reps")
     only = os.environ.get("ONLY")          # e.g. ONLY=OP_STEM_POOL: time just the launches of that kind
-    for rec in plan["ops"]:
+    sp = plan.get("stem_planar") if m.planar_stem else None
+    for idx, rec in enumerate(plan["ops"]):
         if only and KIND.get(int(rec["op"].kind)) != only:
             continue
         arr = (L.Op * 1)()
-        C.memmove(C.addressof(arr[0]), C.addressof(rec["op"]), C.sizeof(L.Op))
+        if sp is not None and idx == sp["index"]:      # the stem launch that reads the clips in place
+            rec = dict(op=sp["op"], params=sp["params"], n_slot=None)
+            C.memmove(C.addressof(arr[0]), C.addressof(rec["op"]), C.sizeof(L.Op))
+            arr[0].ptr[0] = clips.data_ptr()
+        else:
+            C.memmove(C.addressof(arr[0]), C.addressof(rec["op"]), C.sizeof(L.Op))
         arr[0].stream = 0
         if rec["params"] is not None:
             rec["params"].n = n

@@ -52,7 +52,7 @@ class StemParams(C.Structure):
 
 
 class StemPoolParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "cout", "out_halo", "w_rows")]
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "cout", "out_halo", "w_rows", "planar")]
 
 
 class Conv3dParams(C.Structure):
@@ -81,6 +81,7 @@ class Op(C.Structure):
                 ("i", C.c_int32 * 8), ("f", C.c_float * 6)]
 
 
+OP_NOP = 0
 (OP_CONV2D, OP_STEM_CONV, OP_STEM_POOL, OP_CONV3D, OP_LINEAR, OP_MAXPOOL3D, OP_MAXPOOL, OP_AVGPOOL, OP_PACK_CLIPS,
  OP_PREPROCESS, OP_MEAN_T, OP_HEAD, OP_BASIC_BLOCK, OP_BLOCK_ENTRY, OP_MAXPOOL_SPLIT) = range(1, 16)
 

@@ -5,7 +5,7 @@
 
 #include "asl_hip.h"
 
-extern "C" int asl_version(void) { return 103; }
+extern "C" int asl_version(void) { return 104; }
 
 extern "C" const char* asl_strerror(int rc) {
     switch (rc) {
@@ -160,6 +160,9 @@ extern "C" int asl_run_ops(const asl_op* ops, int count, const asl_stream_t* str
             void* const* p = o.ptr;
             const int32_t* i = o.i;
             switch (o.kind) {
+                case ASL_OP_NOP:
+                    rc = 0;
+                    break;
                 case ASL_OP_CONV2D:
                     rc = asl_conv2d_nhwc_bf16((const asl_conv2d_params*)o.params, p[0], p[1], (const float*)p[2],
                                               (const float*)p[3], p[4], p[5], s);

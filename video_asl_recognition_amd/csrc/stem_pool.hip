@@ -238,9 +238,20 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolArgs a)
 [[maybe_unused]] constexpr int kRingBytes = kSlots * kSlot;
 static_assert(kDist % 2 == 0 && 4 + kDist <= kSlots, "prefetch distance");
 
+// PLANAR form: the input is the clip tensor itself, bf16 [n][3][H][W] -- no packed copy, no halo (what lies outside the
+// image is fetched with out-of-range offsets and arrives as zeros).  A row pair is 2 rows x 3 planes x 38 pixels:
+// six 76-byte segments = 114 dwords = two dword-wide LDS-DMA instructions into a 512-byte slot.  K is ordered
+// (filter row, channel, 8 taps): a lane's eight K elements are eight CONSECUTIVE pixels of one plane, so fragments
+// come straight out of the planar rows, and the 21 (row, channel) groups fill 6 MFMAs per channel fragment where the
+// packed form needs 7.  The eight taps of a group start one pixel left of the filter (an even pixel, so every
+// fragment is dword-aligned); that first tap has weight zero.
+[[maybe_unused]] constexpr int kSegDw = 19;               // dwords per segment: (2 * 15 + 8) pixels
+[[maybe_unused]] constexpr int kPSlot = 512;              // planar ring slot
+[[maybe_unused]] constexpr int kPRingBytes = kSlots * kPSlot;
+
 struct StemStripArgs {
-    const char* x;       // packed [n][H+6][W+6][4] bf16
-    const char* w;       // [128][224] bf16 (pack_stem layout)
+    const char* x;       // packed [n][H+6][W+6][4] bf16; PLANAR: [n][3][H][W] bf16
+    const char* w;       // [128][224] bf16 (pack_stem layout); PLANAR: [128][192] (pack_stem_planar layout)
     const float* scale;
     const float* bias;
     char* y;             // [n][PH+2*oh][PW+2*oh][64] bf16
@@ -276,29 +287,46 @@ __device__ __forceinline__ T lds_read(unsigned ad) {
     return v;
 }
 
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+// Four consecutive dwords from the dword-aligned LDS address ad + kImm (two ds_read2_b32: ds_read_b128 wants 16-byte
+// alignment, and the offset fields of ds_read2 reach 1 KiB only).  The addition sits inside the statement so that the
+// compiler cannot hoist one address register per (ring slot, fragment) out of the unrolled loop.
+template <int kImm>
+__device__ __forceinline__ bf16x8 lds_read_4dw(unsigned ad) {
+    i32x2 lo, hi;
+    unsigned t;
+    asm volatile("v_add_u32 %2, %4, %3\n\tds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %2 offset0:2 offset1:3"
+                 : "=v"(lo), "=v"(hi), "=&v"(t) : "v"(ad), "n"(kImm) : "memory");
+    return __builtin_bit_cast(bf16x8, i32x4{lo[0], lo[1], hi[0], hi[1]});
+}
+
+template <bool PLANAR>
 __global__ __launch_bounds__(256, 2) void stem_strip_kernel(const StemStripArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) char lds[4 * kRingBytes];
+    constexpr int NQ = PLANAR ? 6 : 7;                    // K steps (MFMAs per channel fragment) of a conv row
+    constexpr int WK = NQ * 32;                           // weight row length
+    constexpr int SLOT = PLANAR ? kPSlot : kSlot;
+    __shared__ __attribute__((aligned(16))) char lds[4 * kSlots * SLOT];
     __shared__ __attribute__((aligned(16))) float bnt[128];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int Wp = a.W + 6;
-    char* const ring = lds + wave * kRingBytes;
+    char* const ring = lds + wave * (kSlots * SLOT);
     const unsigned ring_ad = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
     constexpr float kNegInf = -__builtin_inff();
 
     // ---- weights -> registers.  Fragment j, row rho holds channel (rho >> 2) * 16 + j * 4 + (rho & 3), so that the
     // lane's 16 results (j, e) are channels fq * 16 + j * 4 + e: 16 consecutive ones.  Rows of channels with a
     // negative BatchNorm scale are negated (sign bit of each bf16), and |scale| is used below.
-    bf16x8 wf[4][7];
+    bf16x8 wf[4][NQ];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ch = (fr >> 2) * 16 + j * 4 + (fr & 3);
         const int flip = (a.scale && a.scale[ch] < 0.f) ? (int)0x80008000 : 0;
 #pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            i32x4 t = *(const i32x4*)(a.w + (ch * 224 + r * 32 + fq * 8) * 2);
+        for (int r = 0; r < NQ; ++r) {
+            i32x4 t = *(const i32x4*)(a.w + (ch * WK + r * 32 + fq * 8) * 2);
             t ^= flip;
             wf[j][r] = __builtin_bit_cast(bf16x8, t);
         }
@@ -318,6 +346,33 @@ __global__ __launch_bounds__(256, 2) void stem_strip_kernel(const StemStripArgs 
     const bool dma_lane = lane < 40;
     const unsigned rd = ring_ad + (2 * fr + 2 * fq) * 8;  // LDS address of the lane's fragment in slot 0, row 0
     constexpr unsigned kOob = 0x80000000u;
+    // PLANAR: lane's dwords of a row pair (instruction i: dword 64 i + lane of the 114) and its six fragment addresses.
+    // Fragment q holds K group g = 4q + fq = (filter row g / 3, channel g % 3); groups 21..23 have zero weights and
+    // re-read group 20.  Filter row r lies in pair (step + (r >> 1)), row r & 1 of it; within MFMAs 1 and 4 the lanes
+    // fq >= 2 sit one pair further on than the lanes fq < 2 (+ kPSlot, or - 15 slots where the ring wraps).
+    int pl_base[2], pl_x[2];
+    unsigned pa[6], pa_wrap[2];
+    constexpr int kNoSrc = (int)0x80000000;
+    const bool second_row0 = lane >= 3 * kSegDw;          // instruction 0: dwords 57..63 already belong to the pair's second row
+    if constexpr (PLANAR) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int d = 64 * i + lane, seg = d / kSegDw, dw = d - seg * kSegDw;
+            // plane, row of the pair (input row = 2 * conv row - 3 + it), pixel pair; the strip's origin is added per task
+            pl_base[i] = d < 6 * kSegDw ? ((seg % 3) * a.H * a.W + (seg / 3 - 3) * a.W + 2 * dw) * 2 : kNoSrc;
+            pl_x[i] = 2 * dw;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            constexpr int kbase[6] = {0, 0, 1, 2, 2, 3};
+            int g = 4 * q + fq;
+            g = g > 20 ? 20 : g;
+            const int r = g / 3, ch = g - 3 * r;
+            pa[q] = ring_ad + ((r >> 1) - kbase[q]) * kPSlot + ((r & 1) * 3 + ch) * (kSegDw * 4) + 4 * fr;
+        }
+        pa_wrap[0] = pa[1] - (fq >= 2 ? kSlots * kPSlot : 0);
+        pa_wrap[1] = pa[4] - (fq >= 2 ? kSlots * kPSlot : 0);
+    }
 
     for (int grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
         const int per_img = a.segs * a.strip_groups;
@@ -332,21 +387,46 @@ __global__ __launch_bounds__(256, 2) void stem_strip_kernel(const StemStripArgs 
         // Row pair k = halo'd input rows 2 * (cy0 + k), +1; columns from halo'd pixel 2 * cx0.  Descriptor rebased to
         // the task so lane offsets stay small; what falls before the tensor (cy0 = -1, cx0 = -1 on the first image)
         // reads as zero, and those conv pixels are masked anyway.
+        // (PLANAR: unpadded rows 2 * (cy0 + k) - 3, -2 of the three planes, 38 pixels from 2 * cx0 - 4; descriptor on
+        // the image; rows and pixel pairs outside it get out-of-range offsets.)
         const long long org = ((long long)img * (a.H + 6) * Wp + (long long)(2 * cy0) * Wp + 2 * cx0) * 8;
-        const long long shift = org > 0 ? org : 0;        // org is a multiple of 16 (Wp even, 2 * cx0 even)
+        const long long shift = PLANAR ? (long long)img * 3 * a.H * a.W * 2 : (org > 0 ? org : 0);   // multiples of 16
         const long long rem_b = a.x_bytes - shift;
-        const unsigned rec = (unsigned)(rem_b > 0x7fffffffLL ? 0x7fffffffLL : rem_b);
+        const unsigned rec = PLANAR ? (unsigned)(3 * a.H * a.W * 2) : (unsigned)(rem_b > 0x7fffffffLL ? 0x7fffffffLL : rem_b);
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + shift), 0, rec, 0x00020000);
         const int rel = (int)(org - shift);               // 0, or negative on the first rows of the first image
         const int lane_src = dma_lane ? rel + drow * Wp * 8 + dch * 16 : -1;
+        int psrc[2];
+        if constexpr (PLANAR) {
+            const int xs = 2 * cx0 - 4;                    // even: a pixel pair is inside the image or outside it as a whole
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = (pl_base[i] != kNoSrc) & ((unsigned)(xs + pl_x[i]) < (unsigned)a.W);
+                psrc[i] = ok ? pl_base[i] + xs * 2 : kNoSrc;
+            }
+        }
         auto dma_pair = [&](int k) {
             // pairs past the task's last one move no data (out-of-range offset: the DMA writes zeros), so the count
             // of instructions in flight is the same on every step
-            const int off = lane_src + k * (2 * Wp * 8);
-            const unsigned vo = (k <= last_pair && lane_src != -1 && off >= 0) ? (unsigned)off : kOob;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ring + (k & (kSlots - 1)) * kSlot),
-                                                     16, vo, 0, 0, 0);
-            asm volatile("" ::: "memory");                // the counted waits need DMAs and stores in program order
+            if constexpr (PLANAR) {
+                const int y0 = 2 * (cy0 + k) - 3;          // first row of the pair
+                const bool k_ok = k <= last_pair;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int y = y0 + ((i == 1) | (int)second_row0);
+                    const bool ok = (psrc[i] != kNoSrc) & k_ok & ((unsigned)y < (unsigned)a.H);
+                    const unsigned vo = ok ? (unsigned)(psrc[i] + 2 * (cy0 + k) * a.W * 2) : kOob;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rs, (__attribute__((address_space(3))) void*)(ring + (k & (kSlots - 1)) * kPSlot + i * 256), 4, vo, 0, 0, 0);
+                    asm volatile("" ::: "memory");
+                }
+            } else {
+                const int off = lane_src + k * (2 * Wp * 8);
+                const unsigned vo = (k <= last_pair && lane_src != -1 && off >= 0) ? (unsigned)off : kOob;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rs, (__attribute__((address_space(3))) void*)(ring + (k & (kSlots - 1)) * kSlot), 16, vo, 0, 0, 0);
+                asm volatile("" ::: "memory");            // the counted waits need DMAs and stores in program order
+            }
         };
         // output through a descriptor on this image: lanes that store nothing get an out-of-range offset
         const long long img_bytes = (long long)ohp * owp * 128;
@@ -362,28 +442,46 @@ __global__ __launch_bounds__(256, 2) void stem_strip_kernel(const StemStripArgs 
         // Fragment r of the conv row in ring position C (= step & (kSlots - 1)): input row 2C + r = pair C + (r >> 1), row
         // r & 1 of it.  The reads are inline assembly on purpose: the compiler orders a visible LDS read behind EVERY
         // LDS-DMA in flight (s_waitcnt vmcnt(0)), which would undo the prefetch distance.
-        auto read6 = [&](auto Cc, bf16x8 (&x)[7]) {
+        auto read6 = [&](auto Cc, bf16x8 (&x)[NQ]) {
             constexpr int C = decltype(Cc)::value;
-            x[0] = lds_read<bf16x8, ((C + 0) & (kSlots - 1)) * kSlot>(rd);
-            x[1] = lds_read<bf16x8, ((C + 0) & (kSlots - 1)) * kSlot + 320>(rd);
-            x[2] = lds_read<bf16x8, ((C + 1) & (kSlots - 1)) * kSlot>(rd);
-            x[3] = lds_read<bf16x8, ((C + 1) & (kSlots - 1)) * kSlot + 320>(rd);
-            x[4] = lds_read<bf16x8, ((C + 2) & (kSlots - 1)) * kSlot>(rd);
-            x[5] = lds_read<bf16x8, ((C + 2) & (kSlots - 1)) * kSlot + 320>(rd);
+            if constexpr (PLANAR) {
+                // fragments 0..3 lie in pairs C .. C + 2 (MFMA 1: the lanes fq >= 2 one pair beyond the others)
+                x[0] = lds_read_4dw<((C + 0) & (kSlots - 1)) * kPSlot>(pa[0]);
+                x[1] = lds_read_4dw<((C + 0) & (kSlots - 1)) * kPSlot>(((C + 0) & (kSlots - 1)) == kSlots - 1 ? pa_wrap[0] : pa[1]);
+                x[2] = lds_read_4dw<((C + 1) & (kSlots - 1)) * kPSlot>(pa[2]);
+                x[3] = lds_read_4dw<((C + 2) & (kSlots - 1)) * kPSlot>(pa[3]);
+            } else {
+                x[0] = lds_read<bf16x8, ((C + 0) & (kSlots - 1)) * kSlot>(rd);
+                x[1] = lds_read<bf16x8, ((C + 0) & (kSlots - 1)) * kSlot + 320>(rd);
+                x[2] = lds_read<bf16x8, ((C + 1) & (kSlots - 1)) * kSlot>(rd);
+                x[3] = lds_read<bf16x8, ((C + 1) & (kSlots - 1)) * kSlot + 320>(rd);
+                x[4] = lds_read<bf16x8, ((C + 2) & (kSlots - 1)) * kSlot>(rd);
+                x[5] = lds_read<bf16x8, ((C + 2) & (kSlots - 1)) * kSlot + 320>(rd);
+            }
         };
-        auto read_last = [&](auto Cc, bf16x8 (&x)[7]) {
+        auto read_last = [&](auto Cc, bf16x8 (&x)[NQ]) {
             constexpr int C = decltype(Cc)::value;
-            x[6] = lds_read<bf16x8, ((C + 3) & (kSlots - 1)) * kSlot>(rd);
+            if constexpr (PLANAR) {
+                // fragments 4, 5 touch pair C + 3, the one that lands last
+                x[4] = lds_read_4dw<((C + 2) & (kSlots - 1)) * kPSlot>(((C + 2) & (kSlots - 1)) == kSlots - 1 ? pa_wrap[1] : pa[4]);
+                x[5] = lds_read_4dw<((C + 3) & (kSlots - 1)) * kPSlot>(pa[5]);
+            } else {
+                x[6] = lds_read<bf16x8, ((C + 3) & (kSlots - 1)) * kSlot>(rd);
+            }
         };
-        // the seven fragments are in their registers once at most the six reads issued since are still out
-        auto frags_ready = [&](bf16x8 (&x)[7]) {
-            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]));
+        // the fragments are in their registers once at most the early reads issued since are still out (LDS operations
+        // complete in order): six ds_read_b128, or four fragments of two ds_read2_b32 each
+        auto frags_ready = [&](bf16x8 (&x)[NQ]) {
+            if constexpr (PLANAR)
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[NQ - 1]));
         };
-        auto mfma_row = [&](const bf16x8 (&xf)[7], f32x4 (&acc)[4]) {
+        auto mfma_row = [&](const bf16x8 (&xf)[NQ], f32x4 (&acc)[4]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 7; ++r)
+            for (int r = 0; r < NQ; ++r)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][r], xf[r], acc[j], 0, 0, 0);
         };
@@ -392,15 +490,17 @@ __global__ __launch_bounds__(256, 2) void stem_strip_kernel(const StemStripArgs 
             typedef __attribute__((ext_vector_type(2))) float f32x2;
             typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
             i32x4 o[2];
-            f32x4 bn[8];                                   // |scale| of the lane's 16 channels, then their biases
-            bn[0] = lds_read<f32x4, 0>(bn_ad);   bn[1] = lds_read<f32x4, 16>(bn_ad);
-            bn[2] = lds_read<f32x4, 32>(bn_ad);  bn[3] = lds_read<f32x4, 48>(bn_ad);
-            bn[4] = lds_read<f32x4, 256>(bn_ad); bn[5] = lds_read<f32x4, 272>(bn_ad);
-            bn[6] = lds_read<f32x4, 288>(bn_ad); bn[7] = lds_read<f32x4, 304>(bn_ad);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]), "+v"(bn[4]), "+v"(bn[5]),
-                         "+v"(bn[6]), "+v"(bn[7]));
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
+                // |scale| and bias of this half's 8 channels (read per half: the registers are scarce here)
+                f32x4 s0, s1, b0, b1;
+                if (half == 0) {
+                    s0 = lds_read<f32x4, 0>(bn_ad);   s1 = lds_read<f32x4, 16>(bn_ad);
+                    b0 = lds_read<f32x4, 256>(bn_ad); b1 = lds_read<f32x4, 272>(bn_ad);
+                } else {
+                    s0 = lds_read<f32x4, 32>(bn_ad);  s1 = lds_read<f32x4, 48>(bn_ad);
+                    b0 = lds_read<f32x4, 288>(bn_ad); b1 = lds_read<f32x4, 304>(bn_ad);
+                }
                 float v[8], h[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = m[half * 2 + (i >> 2)][i & 3];
@@ -409,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void stem_strip_kernel(const StemStripArgs 
                     for (int i = 0; i < 8; ++i) v[i] = col_in ? v[i] : kNegInf;
                 }
                 row_max3_x8(v, h);
-                const f32x4 s0 = bn[half * 2], s1 = bn[half * 2 + 1], b0 = bn[4 + half * 2], b1 = bn[4 + half * 2 + 1];
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0), "+v"(s1), "+v"(b0), "+v"(b1));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int q = 2 * i;                   // values q, q + 1 -> one packed pair
@@ -434,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void stem_strip_kernel(const StemStripArgs 
         // DMAs of the steps since and two stores per pooled row closed in those kDist steps (every other one).  The
         // prologue issues out-of-range (dropped) stores where the steps before the first would have stored, so the count
         // holds from step 0 on.
-        bf16x8 xa[7], xb[7];
+        bf16x8 xa[NQ], xb[NQ];
         f32x4 ve[4], vo_[4], m[4];
 #define STEM_STEP(CM, c, CUR, NXT, ACC)                            \
     {                                                              \
@@ -447,7 +547,9 @@ __global__ __launch_bounds__(256, 2) void stem_strip_kernel(const StemStripArgs 
     }
         // the previous task's fragment reads are behind us (their MFMAs were issued); its trailing DMAs are older than
         // the ones issued now and land first
-        constexpr int kWait = 2 * kDist - 1;
+        // (PLANAR: two DMA instructions per step)
+        constexpr int DPS = PLANAR ? 2 : 1;
+        constexpr int kWait = (kDist - 1) * DPS + kDist;
         auto placeholder_stores = [&]() {
             __builtin_amdgcn_raw_buffer_store_b128(i32x4{0, 0, 0, 0}, ys, kOob, 0, 0);
             asm volatile("" ::: "memory");                // (two instructions: identical neighbours would be merged)
@@ -461,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void stem_strip_kernel(const StemStripArgs 
             dma_pair(4 + k);
             if (!(k & 1)) placeholder_stores();
         }
-        wait_vm<2 * kDist>();                             // pairs 0..3
+        wait_vm<kDist * DPS + kDist>();                   // pairs 0..3
         read6(std::integral_constant<int, 0>{}, xa);
         read_last(std::integral_constant<int, 0>{}, xa);
         // conv row 0 = row 2 * py0 - 1: outside the image for the first segment
@@ -508,8 +610,9 @@ extern "C" int asl_stem_pool_bf16(const asl_stem_pool_params* p, const void* x, 
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)scale & 15) ||
         ((uintptr_t)bias & 15))
         return ASL_EINVAL;
+    if (p->planar && (p->planar != 1 || (long long)p->h * p->w * 6 > 0x7fffffffLL)) return ASL_EINVAL;
     static const bool use_tiles = getenv("ASL_STEM_TILES") && atoi(getenv("ASL_STEM_TILES"));   // A/B: the tile kernel
-    if (!use_tiles) {
+    if (!use_tiles || p->planar) {
         StemStripArgs s;
         s.x = (const char*)x; s.w = (const char*)w; s.scale = scale; s.bias = bias; s.y = (char*)y;
         s.n = p->n; s.H = p->h; s.W = p->w; s.CH = p->h / 2; s.CW = p->w / 2; s.PH = p->h / 4; s.PW = p->w / 4;
@@ -524,8 +627,9 @@ extern "C" int asl_stem_pool_bf16(const asl_stem_pool_params* p, const void* x, 
         if ((long long)(s.PH + 2 * s.out_halo) * (s.PW + 2 * s.out_halo) * 128 > 0x7fffffffLL) return ASL_EINVAL;
         s.ngroups = (int)groups;
         const long long slots = 2LL * device_cus();
-        hipLaunchKernelGGL(stem_strip_kernel, dim3((unsigned)(groups < slots ? groups : slots)), dim3(256), 0,
-                           (hipStream_t)stream, s);
+        const dim3 grid((unsigned)(groups < slots ? groups : slots));
+        if (p->planar) hipLaunchKernelGGL(stem_strip_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, s);
+        else hipLaunchKernelGGL(stem_strip_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, s);
         return (int)hipGetLastError();
     }
     StemPoolArgs a;

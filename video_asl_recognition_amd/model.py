@@ -20,7 +20,8 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib as L
-from .packing import PackedConv, bn_scale_bias, pack_conv, pack_entry_conv, pack_entry_ds, pack_linear, pack_stem
+from .packing import (PackedConv, bn_scale_bias, pack_conv, pack_entry_conv, pack_entry_ds, pack_linear, pack_stem,
+                      pack_stem_planar)
 from .spec import RESNET_LAYERS, SPECS, ModelSpec, param_shapes, resnet_blocks
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -108,6 +109,9 @@ class AslClipModel:
         self.parity_mode = (os.environ.get("ASL_PARITY_MODE", "0") == "1") if parity_mode is None else bool(parity_mode)
         if self.parity_mode and self.spec.backbone not in RESNET_LAYERS:
             raise NotImplementedError("parity mode covers the ResNet backbones")
+        # ResNet stem straight from the bf16 clip tensor (no packed, halo'd copy of the input): ASL_PLANAR_STEM=0 goes
+        # back to pack + packed-input stem (uint8 frames always take that road: preprocess writes the packed form)
+        self.planar_stem = os.environ.get("ASL_PLANAR_STEM", "1") != "0"
         self._w: Dict[str, PackedConv] = {}
         self._fc_w = self._fc_b = None
         self._temporal = None
@@ -135,6 +139,7 @@ class AslClipModel:
         elif spec.backbone in RESNET_LAYERS:
             s, b = bn_scale_bias(sd, "backbone.bn1", 1e-5, dev)
             w["stem"] = pack_stem(sd["backbone.conv1.weight"], dev, s, b)
+            w["stem_planar"] = pack_stem_planar(sd["backbone.conv1.weight"], dev, s, b)
             nconv = 2 if RESNET_LAYERS[spec.backbone][0] == "basic" else 3
             split = self.parity_mode
             for prefix, cin, planes, stride, ds in resnet_blocks(spec.backbone):
@@ -193,6 +198,8 @@ class AslClipModel:
                                out_s2d=int(y.cells), out_split=int(pm))
             add(L.OP_CONV2D, p, (x.t, pc.w, pc.scale, pc.bias, res.t if res else None, y.t), conv=True, keep=(x, y, res, pc))
 
+        stem_planar = None
+
         def stem_op(pc: PackedConv, x0: torch.Tensor, in_halo, y: Act, stride, pad, relu):
             kd, kh, kw = pc.k
             p = L.StemParams(n=0, h=S, w=S, in_halo=in_halo, cout=pc.cout, kh=kh, kw=kw, stride=stride, pad=pad,
@@ -225,6 +232,13 @@ class AslClipModel:
                 pc = self._w["stem"]
                 sp = L.StemPoolParams(n=0, h=S, w=S, cout=pc.cout, out_halo=x.halo, w_rows=pc.w_rows)
                 add(L.OP_STEM_POOL, sp, (x0, pc.w, pc.scale, pc.bias, x.t), conv=True, keep=(x, pc))
+                # the same launch reading the bf16 clip tensor itself (no packed copy): swapped in per call when the
+                # caller hands over clips rather than uint8 frames; its source pointer is set per chunk
+                pp = self._w["stem_planar"]
+                spp = L.StemPoolParams(n=0, h=S, w=S, cout=pp.cout, out_halo=x.halo, w_rows=pp.w_rows, planar=1)
+                stem_planar = dict(op=L.make_op(L.OP_STEM_POOL, spp, [None, pp.w.data_ptr(), pp.scale.data_ptr(),
+                                                                     pp.bias.data_ptr(), x.t.data_ptr()]),
+                                   params=spp, index=len(ops) - 1, keep=(pp, x))
             basic = RESNET_LAYERS[spec.backbone][0] == "basic"
             blocks = list(resnet_blocks(spec.backbone))
             cells_ok = basic and self.s2d_entry and self.conv_variant in (0, L.CONV_PP) and not pm
@@ -281,7 +295,7 @@ class AslClipModel:
                     pool.put(idt)
                 pool.put(x)
                 x = y
-        plan = {"x0": x0, "in_halo": in_halo, "ops": ops, "last": x, "pool": pool, "nmax": nmax}
+        plan = {"x0": x0, "in_halo": in_halo, "ops": ops, "last": x, "pool": pool, "nmax": nmax, "stem_planar": stem_planar}
         return plan
 
     def _group_array(self, plans, g: int):
@@ -353,7 +367,21 @@ class AslClipModel:
                 c0 = starts[g0 + j]
                 n = min(step, n_total - c0)
                 plan = plans[j]
-                fill_x0(arr[j], c0, n, plan["x0"].data_ptr(), plan["in_halo"])
+                direct = fill_x0(arr[j], c0, n, plan["x0"].data_ptr(), plan["in_halo"])
+                sp = plan["stem_planar"]
+                if sp is not None:
+                    # the stem launch of this chunk: on the packed input the fill op writes, or (fill_x0 returned the
+                    # address of the chunk's bf16 clips) on those directly, with no fill
+                    k = g + sp["index"] * g + j
+                    rec = sp if direct else plan["ops"][sp["index"]]
+                    C.memmove(C.addressof(arr[k]), C.addressof(rec["op"]), C.sizeof(L.Op))
+                    arr[k].stream = j
+                    if direct:
+                        arr[k].ptr[0] = direct
+                        arr[j].kind = L.OP_NOP
+                        sp["params"].n = n
+                elif direct:
+                    raise RuntimeError("this plan has no launch that reads clips in place")
                 for rec in plan["ops"]:
                     if rec["params"] is not None:
                         rec["params"].n = n
@@ -391,11 +419,17 @@ class AslClipModel:
         """clips [B,T,3,S,S] -> per-frame features fp32 [B*T, F] (and their bf16 copy)."""
         clips = self._check_clips(clips)
         B, T, _, S, _ = clips.shape
+        # (the conditions under which _build_plan lays down the in-place stem launch)
+        planar = (self.planar_stem and self.spec.backbone in RESNET_LAYERS and self.fused_stem and not self.parity_mode)
+        if planar and clips.dtype != torch.bfloat16:
+            clips = clips.to(torch.bfloat16)            # the rounding the packed copy would apply (nearest even)
         esz = clips.element_size()
         in_f32 = int(clips.dtype == torch.float32)
         base = clips.data_ptr()
 
         def fill(op, c0, n, x0_ptr, in_halo):
+            if planar:                                    # the stem kernel reads the clips where they lie
+                return base + c0 * 3 * S * S * 2
             op.kind = L.OP_PACK_CLIPS
             op.ptr[0], op.ptr[1] = base + c0 * 3 * S * S * esz, x0_ptr
             op.i[0], op.i[1], op.i[2], op.i[3] = in_f32, n, S, in_halo

@@ -69,6 +69,20 @@ def pack_stem(w: torch.Tensor, device, scale=None, bias=None) -> PackedConv:
     return PackedConv(p, scale, bias, cout, 4, (1, kh, kw), w_rows)
 
 
+def pack_stem_planar(w: torch.Tensor, device, scale=None, bias=None) -> PackedConv:
+    """ResNet stem weights [cout, 3, 7, 7] for the planar-input form of the fused stem kernel: bf16 [w_rows][6 * 32],
+    K ordered (filter row, channel, 8 taps): group g = 3 * row + channel holds tap slots 0..7, slot 0 (the pixel left
+    of the filter) zero, slots 1..7 = taps 0..6; groups 21..23 zero."""
+    w = w.to(torch.float32)
+    cout, cin, kh, kw = w.shape
+    assert cin == 3 and kh == 7 and kw == 7
+    w_rows = _round_up(cout, 128)
+    p = torch.zeros(w_rows, 24, 8, dtype=torch.float32)
+    p[:cout, :21, 1:] = w.permute(0, 2, 1, 3).reshape(cout, 21, 7)      # [cout][row][ch][tap]
+    p = p.reshape(w_rows, 192).to(torch.bfloat16).contiguous().to(device)
+    return PackedConv(p, scale, bias, cout, 3, (1, kh, kw), w_rows)
+
+
 def pack_linear(w: torch.Tensor, device, bias=None, k_phys: Optional[int] = None) -> PackedConv:
     """nn.Linear weight [n, k] -> bf16 [w_rows][k_phys] (k zero-padded to a multiple of 32)."""
     n, k = w.shape
