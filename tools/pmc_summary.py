@@ -4,8 +4,10 @@ counter.  HBM traffic per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 
 128-byte read requests at 64 bytes, so wide coalesced reads are doubled; WRITE_SIZE is exact.
 
 python tools/pmc_summary.py [--json out.json --frames-per-chunk N] a.csv b.csv ...
-With --json, also writes the figures bench.py reports next to its timing: HBM bytes of all path kernels
-(asl_detail::*) per chunk of frames -- total bytes / launches of the stem kernel, which runs once per chunk --
+With --json, also writes the figures bench.py reports next to its timing: HBM bytes of the headline path's kernels
+per chunk of frames -- the stem launch that reads the clips in place (once per chunk) plus, for the kernels the
+uint8-frames leg of the bench shares (blocks, convolutions, pools, head), their bytes per launch x launches per chunk
+over both legs; the kernels only that leg runs (preprocess, packed-input stem, pack, softmax) are left out --
 and the MFMA-busy ratio of the conv kernels, SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x busy cycles), busy
 cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs)."""
 import csv
@@ -13,7 +15,7 @@ import json
 import sys
 from collections import defaultdict
 
-CONV = ("stem_pool_kernel", "block_c64_pair_kernel", "block_c64_kernel", "conv3x3_c64_kernel", "conv3x3_pp_kernel", "conv3x3_wide_kernel", "conv3x3_patch_kernel",
+CONV = ("stem_pool_kernel", "stem_strip_kernel", "block_c64_pair_kernel", "block_c64_kernel", "conv3x3_c64_kernel", "conv3x3_pp_kernel", "conv3x3_wide_kernel", "conv3x3_patch_kernel",
         "gather_gemm_kernel")
 
 
@@ -50,7 +52,9 @@ def main(argv):
             hbm[k] = (per * 1024, n)
             print(f"{k},HBM_BYTES_corrected,{n},{per * 1024 * n:.6g},{per * 1024:.6g}")
     if json_out:
-        stem = [k for k in hbm if "stem_pool_kernel" in k]
+        stem = [k for k in hbm if "stem_strip_kernel<true>" in k]          # the headline path's stem
+        stems_all = [k for k in hbm if "stem_strip_kernel" in k or "stem_pool_kernel" in k]
+        other_leg = ("stem_strip_kernel<false>", "stem_pool_kernel", "preprocess_kernel", "softmax_topk_kernel", "pack_clips")
         import os
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
         from video_asl_recognition_amd._lib import source_hash
@@ -58,8 +62,12 @@ def main(argv):
         out = {"frames_per_chunk": fpc, "source_hash": source_hash(), "per_kernel": {}}
         if stem:
             chunks = hbm[stem[0]][1]
-            tot = sum(b * n for k, (b, n) in hbm.items() if "asl_detail" in k)
-            out["hbm_bytes_per_chunk"] = tot / chunks
+            chunks_all = sum(hbm[k][1] for k in stems_all)
+            tot = hbm[stem[0]][0]
+            for k, (b, n) in hbm.items():
+                if "asl_detail" in k and k != stem[0] and not any(o in k for o in other_leg):
+                    tot += b * n / chunks_all
+            out["hbm_bytes_per_chunk"] = tot
             out["chunks_profiled"] = chunks
         busy = mf = 0.0
         for k in agg:
