@@ -600,6 +600,11 @@ def test_maxpool_exact(gpu):
                                          ((1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 5, 28, 26, 64)),
                                          ((3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 4, 14, 14, 192)),
                                          ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 3, 7, 9, 32)),
+                                         # the rolling stride-1 kernel: several depth segments with a short last one, rows
+                                         # whose last group of outputs is partial, no padding at all
+                                         # (it takes launches of 64 k lanes and more)
+                                         ((3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 19, 30, 30, 512)),
+                                         ((3, 3, 3), (1, 1, 1), (0, 0, 0), (3, 12, 29, 27, 512)),
                                          ((2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 14, 14, 832)),
                                          ((2, 3, 2), (1, 2, 1), (0, 1, 0), (1, 4, 9, 7, 16))])
 def test_maxpool3d_exact(gpu, k, s, p, shape):

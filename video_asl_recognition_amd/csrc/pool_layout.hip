@@ -274,6 +274,73 @@ __global__ __launch_bounds__(256) void maxpool_fixed_kernel(const PoolArgs a, co
     }
 }
 
+// 3x3x3 / stride 1 (the pooling branch of every Inception block): a lane walks DS output planes for its WPT outputs of a
+// row and 8 channels.  Each input plane is reduced once, over its three rows and then over the three columns of every
+// output, to a per-plane maximum that the three output planes around it share (kept in registers, rolled from plane to
+// plane): 18 loads per plane for four outputs -- 5.6 loads per output with DS = 8, against 13.5 when every output plane
+// starts over.
+template <int WPT, int DS>
+__global__ __launch_bounds__(256) void maxpool333_roll_kernel(const PoolArgs a, const FastDiv dC8, const FastDiv dWG, const FastDiv dOH,
+                                                              const FastDiv dSEG, const int wgroups, const int nseg) {
+    constexpr int NCOL = WPT + 2;
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned total = (unsigned)a.n * nseg * a.oh * wgroups * a.c8;       // < 2^31, checked by the host
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        unsigned t = fdiv(i, dC8);
+        const int c = (int)(i - t * a.c8);
+        unsigned q = fdiv(t, dWG);
+        const int w0 = (int)(t - q * wgroups) * WPT;
+        t = q; q = fdiv(t, dOH);
+        const int h = (int)(t - q * a.oh);
+        t = q; q = fdiv(t, dSEG);
+        const int d0 = (int)(t - q * nseg) * DS;
+        const long long n = q;
+        const int nd = a.od - d0 < DS ? a.od - d0 : DS;                        // output planes of this lane
+        const int nout = a.ow - w0 < WPT ? a.ow - w0 : WPT;                    // outputs per row that exist
+        const int ncol = nout + 2;
+        const short* src = a.x + n * a.in_sn + (long long)d0 * a.in_sd + (long long)h * a.in_sh + (long long)w0 * a.in_sw +
+                           a.in_off0 + 8 * c;                                  // input plane d0 - 1 (tap 0 of output plane d0)
+        short* dst = a.y + n * a.out_sn + (long long)d0 * a.out_sd + (long long)h * a.out_sh + (long long)w0 * a.out_sw + a.out_off0 + 8 * c;
+        bf16x8 pa[WPT], pb[WPT];                                               // maxima of the two planes before the current one
+#pragma unroll
+        for (int o = 0; o < WPT; ++o) pa[o] = pb[o] = zero;
+        for (int p = 0; p < nd + 2; ++p) {
+            const short* pl = src + (long long)p * a.in_sd;
+            bf16x8 col[NCOL];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                // columns past the row's last output are not needed: they re-read the last needed one, so that all 18 loads
+                // of the plane go out together (a predicate per column would put a branch and a wait between them)
+                const int jj = j < ncol ? j : ncol - 1;
+                const bf16x8 r0 = *(const bf16x8*)(pl + jj * a.in_sw);
+                const bf16x8 r1 = *(const bf16x8*)(pl + a.in_sh + jj * a.in_sw);
+                const bf16x8 r2 = *(const bf16x8*)(pl + 2 * a.in_sh + jj * a.in_sw);
+                col[j] = __builtin_elementwise_max(__builtin_elementwise_max(r0, r1), r2);
+            }
+#pragma unroll
+            for (int o = 0; o < WPT; ++o) {
+                const bf16x8 pm = __builtin_elementwise_max(__builtin_elementwise_max(col[o], col[o + 1]), col[o + 2]);
+                if (p >= 2 && o < nout)
+                    *(bf16x8*)(dst + (long long)(p - 2) * a.out_sd + (long long)o * a.out_sw) =
+                        __builtin_elementwise_max(__builtin_elementwise_max(pa[o], pb[o]), pm);
+                pa[o] = pb[o];
+                pb[o] = pm;
+            }
+        }
+    }
+}
+
+template <int WPT, int DS>
+static int launch_maxpool333_roll(const PoolArgs& a, hipStream_t stream) {
+    const int wgroups = (a.ow + WPT - 1) / WPT, nseg = (a.od + DS - 1) / DS;
+    const long long total = (long long)a.n * nseg * a.oh * wgroups * a.c8;
+    if (total >= 0x7fffffffLL) return -1;
+    hipLaunchKernelGGL((maxpool333_roll_kernel<WPT, DS>), dim3(grid_for(total)), dim3(256), 0, stream, a,
+                       make_fastdiv((unsigned)a.c8), make_fastdiv((unsigned)wgroups), make_fastdiv((unsigned)a.oh),
+                       make_fastdiv((unsigned)nseg), wgroups, nseg);
+    return (int)hipGetLastError();
+}
+
 template <int KD, int KH, int KW, int SW, int WPT>
 static int launch_maxpool_fixed(const PoolArgs& a, hipStream_t stream) {
     const int wgroups = (a.ow + WPT - 1) / WPT;
@@ -521,7 +588,11 @@ extern "C" int asl_maxpool3d_ndhwc(const asl_pool3d_params* p, const void* x, vo
     a.out_sn = (long long)odp * ohp * owp * p->c;
     a.out_off0 = p->out_halo_d * a.out_sd + p->out_halo * a.out_sh + p->out_halo * a.out_sw;
     int e = -1;
-    if (a.kd == 3 && a.kh == 3 && a.kw == 3 && a.sw == 1) e = launch_maxpool_fixed<3, 3, 3, 1, 4>(a, (hipStream_t)stream);
+    // (rolling over depth pays once there are lanes enough to hide its serial walk: below ~64 k lanes the per-output kernel)
+    if (a.kd == 3 && a.kh == 3 && a.kw == 3 && a.sd == 1 && a.sh == 1 && a.sw == 1 &&
+        (long long)a.n * ((a.od + 7) / 8) * a.oh * ((a.ow + 3) / 4) * a.c8 >= 65536)
+        e = launch_maxpool333_roll<4, 8>(a, (hipStream_t)stream);
+    else if (a.kd == 3 && a.kh == 3 && a.kw == 3 && a.sw == 1) e = launch_maxpool_fixed<3, 3, 3, 1, 4>(a, (hipStream_t)stream);
     else if (a.kd == 3 && a.kh == 3 && a.kw == 3 && a.sw == 2) e = launch_maxpool_fixed<3, 3, 3, 2, 2>(a, (hipStream_t)stream);
     else if (a.kd == 1 && a.kh == 3 && a.kw == 3 && a.sw == 2) e = launch_maxpool_fixed<1, 3, 3, 2, 2>(a, (hipStream_t)stream);
     else if (a.kd == 2 && a.kh == 2 && a.kw == 2 && a.sw == 2) e = launch_maxpool_fixed<2, 2, 2, 2, 2>(a, (hipStream_t)stream);

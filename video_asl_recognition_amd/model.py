@@ -86,7 +86,9 @@ class AslClipModel:
         # launch): its deep layers are a few hundred pixels per clip, and four clips per launch left most CUs without a
         # tile (16 x 64: 10.95 -> 8.01 ms per forward)
         if frames_per_chunk is None:
-            frames_per_chunk = 1024 if self.spec.backbone == "i3d" else 256
+            # frames per backbone launch: enough that the late, small layers fill whole rounds of workgroups (ResNet-18:
+            # 640 frames = 1 960 / 980 / 256 tiles on 512 / 512 / 256 slots; I3D: 16 clips); ResNet-50 is flat in it
+            frames_per_chunk = {"i3d": 1024, "resnet18": 640}.get(self.spec.backbone, 256)
         self.frames_per_chunk = int(frames_per_chunk)
         self.streams = int(streams)
         self._streams: List[torch.cuda.Stream] = []
