@@ -390,6 +390,10 @@ CONV3D_CASES = [
     (1, 5, 12, 17, 64, 192, 192, 0),
     (2, 3, 20, 20, 160, 320, 832, 256),
     (5, 2, 7, 7, 64, 48, 64, 16),
+    # widths whose last 128-channel tile is partly empty: 32 live channels in one wave's 64 and none in the other's,
+    # 64 + 32 live ones (the large-tile kernel skips reads and MFMAs of 32-channel pairs past the output width)
+    (1, 4, 14, 14, 160, 288, 288, 0),
+    (2, 3, 9, 11, 128, 224, 256, 32),
 ]
 
 

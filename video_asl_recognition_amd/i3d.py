@@ -89,7 +89,12 @@ class I3dPlan:
         self.spec, self.nmax, self.T, self.dev = spec, nmax, T, dev
         S = spec.size
         pool = _Pool3(nmax, dev)
-        self.ops: List = []
+        self.ops: List = []            # every launch, in single-stream order: op(n, stream)
+        # The same launches as a schedule over three streams: ("op", index into ops, stream) | ("fork",) | ("join",).
+        # The branches of an Inception block are independent until the concatenated output is complete, and from the
+        # 14 x 14 layers on a single launch no longer fills the chip, so branch 1 runs on stream 0, branches 2 and 0 on
+        # stream 1 and the pooled branch on stream 2; "fork" makes streams 1 and 2 wait for stream 0, "join" the reverse.
+        self.sched: List = []
         self.x0 = torch.zeros(nmax, T + 6, S + 6, S + 6, 4, dtype=torch.bfloat16, device=dev)
 
         def conv(pc: PackedConv, x: Act3, y: Act3, coff=0, stride=1):
@@ -103,6 +108,7 @@ class I3dPlan:
                 p.n = n
                 L.check(L.lib.asl_conv3d_ndhwc_bf16(C.byref(p), *args, stream), "conv3d")
             self.ops.append(run)
+            return len(self.ops) - 1
 
         def maxpool(x: Act3, y: Act3, k, s, pad):
             p = L.Pool3dParams(n=0, d=x.d, h=x.h, w=x.w, c=x.c, in_halo_d=x.hd, in_halo=x.hh, kd=k[0], kh=k[1], kw=k[2],
@@ -113,6 +119,7 @@ class I3dPlan:
                 p.n = n
                 L.check(L.lib.asl_maxpool3d_ndhwc(C.byref(p), _ptr(x.t), _ptr(y.t), stream), "maxpool3d")
             self.ops.append(run)
+            return len(self.ops) - 1
 
         # ---- stem 7x7x7 / 2 on packed RGB: a gather-GEMM with one tap per (kd, kh) filter row ----------
         D1, H1 = (T + 6 - 7) // 2 + 1, S // 2
@@ -164,22 +171,31 @@ class I3dPlan:
                 ctot = wd[0] + wd[2] + wd[4] + wd[5]
                 halo = 0 if name == "mixed_5c" else 1          # the last block feeds the global average pool
                 y = pool.get(x.d, x.h, x.w, _r32(ctot), halo, halo)
-                conv(w[name + ".b0"], x, y, 0)
+                first = len(self.ops)
+                self.sched += [("op", i, 0) for i in range(len(self.sched_done()), first)]
+                b0 = conv(w[name + ".b0"], x, y, 0)
                 t1 = pool.get(x.d, x.h, x.w, _r32(wd[1]), 1, 1)
-                conv(w[name + ".b1a"], x, t1)
-                conv(w[name + ".b1b"], t1, y, wd[0])
+                b1a = conv(w[name + ".b1a"], x, t1)
+                b1b = conv(w[name + ".b1b"], t1, y, wd[0])
                 t2 = pool.get(x.d, x.h, x.w, _r32(wd[3]), 1, 1)
-                conv(w[name + ".b2a"], x, t2)
-                conv(w[name + ".b2b"], t2, y, wd[0] + wd[2])
+                b2a = conv(w[name + ".b2a"], x, t2)
+                b2b = conv(w[name + ".b2b"], t2, y, wd[0] + wd[2])
                 t3 = pool.get(x.d, x.h, x.w, x.c, 0, 0)
-                maxpool(x, t3, (3, 3, 3), (1, 1, 1), (1, 1, 1))
-                conv(w[name + ".b3b"], t3, y, wd[0] + wd[2] + wd[4])
+                b3a = maxpool(x, t3, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+                b3b = conv(w[name + ".b3b"], t3, y, wd[0] + wd[2] + wd[4])
+                self.sched += [("fork",), ("op", b1a, 0), ("op", b2a, 1), ("op", b3a, 2), ("op", b1b, 0), ("op", b2b, 1),
+                               ("op", b3b, 2), ("op", b0, 1), ("join",)]
                 for t in (t1, t2, t3):
                     pool.put(t)
             pool.put(x)
             x = y
+        self.sched += [("op", i, 0) for i in range(len(self.sched_done()), len(self.ops))]
+        assert sorted(self.sched_done()) == list(range(len(self.ops)))
         self.last = x
         self.pool = pool
+
+    def sched_done(self):
+        return [e[1] for e in self.sched if e[0] == "op"]
 
     def nbytes(self):
         return sum(a.t.numel() * 2 for a in self.pool.all) + self.x0.numel() * 2

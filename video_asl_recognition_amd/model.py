@@ -92,6 +92,7 @@ class AslClipModel:
         self.frames_per_chunk = int(frames_per_chunk)
         self.streams = int(streams)
         self._streams: List[torch.cuda.Stream] = []
+        self._i3d_events: List[torch.cuda.Event] = []
         self._plan = None
         self._groups: Dict[int, tuple] = {}
         # diagnostics / A-B runs: force one conv kernel variant (L.CONV_*), run stem and max-pool unfused
@@ -481,8 +482,11 @@ class AslClipModel:
             for b in range(n):      # frames of clip b sit behind 3 zero halo frames of its own padded depth axis
                 dst = plan.x0.data_ptr() + ((b * (T + 6) + 3) * plane) * 2
                 fill_frames((b0 + b) * T, T, C.c_void_p(dst), stream)
-            for op in plan.ops:
-                op(n, stream)
+            if self.streams > 1:
+                self._run_i3d_sched(plan, n)
+            else:
+                for op in plan.ops:
+                    op(n, stream)
             L.check(L.lib.asl_avgpool_nhwc(_ptr(last.t), n * D, last.h, last.w, last.c, last.hh,
                                            C.c_void_p(frame_feats.data_ptr() + b0 * D * last.c * 4), None, 0, 0, stream),
                     "avgpool")
@@ -492,6 +496,29 @@ class AslClipModel:
         L.check(L.lib.asl_head_f32(_ptr(pooled), B, last.c, _ptr(self._fc_w), _ptr(self._fc_b), spec.num_classes,
                                    _ptr(logits), stream), "head")
         return logits
+
+    def _run_i3d_sched(self, plan, n: int):
+        """The plan's launches over three streams: the caller's and two side streams, forked and joined around every
+        Inception block (I3dPlan.sched)."""
+        main = torch.cuda.current_stream()
+        side = self._side_streams(2)
+        st = [main] + side
+        hs = [C.c_void_p(s_.cuda_stream) for s_ in st]
+        if not self._i3d_events:
+            self._i3d_events = [torch.cuda.Event() for _ in range(3)]
+        ev = self._i3d_events
+        for e in plan.sched:
+            if e[0] == "op":
+                plan.ops[e[1]](n, hs[e[2]])
+            elif e[0] == "fork":
+                ev[0].record(main)
+                side[0].wait_event(ev[0])
+                side[1].wait_event(ev[0])
+            else:
+                ev[1].record(side[0])
+                ev[2].record(side[1])
+                main.wait_event(ev[1])
+                main.wait_event(ev[2])
 
     @torch.no_grad()
     def forward(self, clips: torch.Tensor, keypoints: Optional[torch.Tensor] = None) -> torch.Tensor:
