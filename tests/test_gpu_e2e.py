@@ -190,6 +190,25 @@ def test_chunking_and_streams_do_not_change_results(gpu):
         del m
 
 
+def test_i3d_streams_and_chunk_pairs_do_not_change_results(gpu):
+    """The 3-D backbone on one stream, with its Inception branches on three streams, and with chunks paired side by
+    side on six streams (one-clip chunks: clips 0 and 1 together, clip 2 alone) gives the same logits bit for bit."""
+    from video_asl_recognition_amd import AslClipModel
+    clips = O.make_clips(3, 16, 224, 8).cuda()
+    ref = None
+    for chunk, streams in ((1024, 1), (1024, 2), (16, 2), (32, 2)):
+        m = AslClipModel("i3d", frames_per_chunk=chunk, streams=streams, seed=2)
+        y = m(clips).clone()
+        y2 = m(clips).clone()                       # workspaces and events are reused by the second call
+        assert torch.equal(y, y2)
+        if ref is None:
+            ref = y
+            assert bool(torch.isfinite(y).all()) and float((y[0] - y[1]).abs().max()) > 0
+        else:
+            assert torch.equal(y, ref), f"chunk={chunk} streams={streams} changed the logits"
+        del m
+
+
 def test_fused_basic_blocks_give_the_same_logits(gpu, monkeypatch):
     """layer 1 run as one kernel per BasicBlock (the default) against the two-launch form and the oracle"""
     om, m1 = _model("resnet18_mean")

@@ -93,6 +93,7 @@ class AslClipModel:
         self.streams = int(streams)
         self._streams: List[torch.cuda.Stream] = []
         self._i3d_events: List[torch.cuda.Event] = []
+        self._i3d_plans: List = []
         self._plan = None
         self._groups: Dict[int, tuple] = {}
         # diagnostics / A-B runs: force one conv kernel variant (L.CONV_*), run stem and max-pool unfused
@@ -174,6 +175,7 @@ class AslClipModel:
             from .temporal import build_temporal
             self._temporal = build_temporal(spec, sd, dev)
         self._plan = None
+        self._i3d_plans = []
         self._groups = {}
         return self
 
@@ -464,61 +466,76 @@ class AslClipModel:
     # ------------------------------------------------------------------ I3D
     def _run_i3d(self, B: int, T: int, fill_frames):
         """fill_frames(f0, n, dst_ptr, stream) writes frames [f0, f0+n) (flattened over B*T) as packed
-        [n][S+6][S+6][4] at dst_ptr.  Clips run through the 3-D backbone `clips_per_chunk` at a time."""
+        [n][S+6][S+6][4] at dst_ptr.  Clips run through the 3-D backbone a chunk (16 clips of 64 frames) at a time, the
+        Inception branches of a chunk on three streams (I3dPlan.sched).  A batch of two or more full chunks runs them in
+        pairs side by side, each on a main stream of its own plus two branch streams, launches issued alternately: one
+        chunk's memory-bound pools then run under the other's convolutions (32 x 64: 12.6 -> 12.0 ms; with chunks smaller
+        than 16 clips the pairing loses more to under-filled launches than it gains: 16 x 64 as 8 + 8 takes 6.55 ms
+        against 6.32)."""
         from .i3d import I3dPlan
         spec, dev, S = self.spec, self.device, self.spec.size
         per = max(1, self.frames_per_chunk // T)
-        nmax = min(B, per)
-        plan = self._plan
-        if not isinstance(plan, I3dPlan) or plan.T != T or plan.nmax < nmax:
-            plan = self._plan = I3dPlan(spec, self._w, nmax, T, dev)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        last = plan.last
-        D, Fdim = last.d, spec.feat_dim
+        G = 2 if self.streams > 1 and B >= 2 * per else 1
+        nmax = min(per, (B + G - 1) // G)
+        plans = self._i3d_plans
+        if len(plans) < G or plans[0].T != T or plans[0].nmax < nmax:
+            plans = self._i3d_plans = [I3dPlan(spec, self._w, nmax, T, dev) for _ in range(G)]
+            self._plan = plans[0]
+        main = torch.cuda.current_stream()
+        last = plans[0].last
+        D = last.d
         frame_feats = torch.empty(B * D, last.c, dtype=torch.float32, device=dev)
         plane = (S + 6) * (S + 6) * 4
-        for b0 in range(0, B, plan.nmax):
-            n = min(plan.nmax, B - b0)
-            for b in range(n):      # frames of clip b sit behind 3 zero halo frames of its own padded depth axis
-                dst = plan.x0.data_ptr() + ((b * (T + 6) + 3) * plane) * 2
-                fill_frames((b0 + b) * T, T, C.c_void_p(dst), stream)
-            if self.streams > 1:
-                self._run_i3d_sched(plan, n)
-            else:
-                for op in plan.ops:
-                    op(n, stream)
-            L.check(L.lib.asl_avgpool_nhwc(_ptr(last.t), n * D, last.h, last.w, last.c, last.hh,
-                                           C.c_void_p(frame_feats.data_ptr() + b0 * D * last.c * 4), None, 0, 0, stream),
-                    "avgpool")
+        if self.streams <= 1:
+            groups = [(main, [main, main, main])]
+        else:
+            side = self._side_streams(5)
+            groups = [(main, [main, side[0], side[1]]), (side[2], [side[2], side[3], side[4]])]
+            if not self._i3d_events:
+                self._i3d_events = [torch.cuda.Event() for _ in range(8)]
+        ev = self._i3d_events
+        chunks = [(b0, min(nmax, B - b0)) for b0 in range(0, B, nmax)]
+        for c0 in range(0, len(chunks), G):
+            act = [(plans[g], groups[g], chunks[c0 + g]) for g in range(min(G, len(chunks) - c0))]
+            if G > 1:                                      # the second group starts once the inputs are there
+                ev[6].record(main)
+                groups[1][0].wait_event(ev[6])
+            for plan, (gm, _), (b0, n) in act:
+                h = C.c_void_p(gm.cuda_stream)
+                for b in range(n):  # frames of clip b sit behind 3 zero halo frames of its own padded depth axis
+                    dst = plan.x0.data_ptr() + ((b * (T + 6) + 3) * plane) * 2
+                    fill_frames((b0 + b) * T, T, C.c_void_p(dst), h)
+            hs = [[C.c_void_p(s_.cuda_stream) for s_ in st] for _, (_, st), _ in act]
+            for e in plans[0].sched:                       # every plan has the same schedule
+                for gi, (plan, (gm, st), (b0, n)) in enumerate(act):
+                    if e[0] == "op":
+                        plan.ops[e[1]](n, hs[gi][e[2]])
+                    elif self.streams <= 1:
+                        continue
+                    elif e[0] == "fork":
+                        ev[3 * gi].record(gm)
+                        st[1].wait_event(ev[3 * gi])
+                        st[2].wait_event(ev[3 * gi])
+                    else:
+                        ev[3 * gi + 1].record(st[1])
+                        ev[3 * gi + 2].record(st[2])
+                        gm.wait_event(ev[3 * gi + 1])
+                        gm.wait_event(ev[3 * gi + 2])
+            for plan, (gm, _), (b0, n) in act:
+                lt = plan.last
+                L.check(L.lib.asl_avgpool_nhwc(_ptr(lt.t), n * D, lt.h, lt.w, lt.c, lt.hh,
+                                               C.c_void_p(frame_feats.data_ptr() + b0 * D * lt.c * 4), None, 0, 0,
+                                               C.c_void_p(gm.cuda_stream)), "avgpool")
+            if len(act) > 1:
+                ev[7].record(groups[1][0])
+                main.wait_event(ev[7])
+        stream = C.c_void_p(main.cuda_stream)
         pooled = torch.empty(B, last.c, dtype=torch.float32, device=dev)
         L.check(L.lib.asl_window_mean_t_f32(_ptr(frame_feats), B, D, last.c, min(2, D), _ptr(pooled), stream), "window_mean")
         logits = torch.empty(B, spec.num_classes, dtype=torch.float32, device=dev)
         L.check(L.lib.asl_head_f32(_ptr(pooled), B, last.c, _ptr(self._fc_w), _ptr(self._fc_b), spec.num_classes,
                                    _ptr(logits), stream), "head")
         return logits
-
-    def _run_i3d_sched(self, plan, n: int):
-        """The plan's launches over three streams: the caller's and two side streams, forked and joined around every
-        Inception block (I3dPlan.sched)."""
-        main = torch.cuda.current_stream()
-        side = self._side_streams(2)
-        st = [main] + side
-        hs = [C.c_void_p(s_.cuda_stream) for s_ in st]
-        if not self._i3d_events:
-            self._i3d_events = [torch.cuda.Event() for _ in range(3)]
-        ev = self._i3d_events
-        for e in plan.sched:
-            if e[0] == "op":
-                plan.ops[e[1]](n, hs[e[2]])
-            elif e[0] == "fork":
-                ev[0].record(main)
-                side[0].wait_event(ev[0])
-                side[1].wait_event(ev[0])
-            else:
-                ev[1].record(side[0])
-                ev[2].record(side[1])
-                main.wait_event(ev[1])
-                main.wait_event(ev[2])
 
     @torch.no_grad()
     def forward(self, clips: torch.Tensor, keypoints: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -600,7 +617,7 @@ class AslClipModel:
             return 0
         if isinstance(self._plan, list):
             return sum(p["pool"].nbytes() + p["x0"].numel() * 2 for p in self._plan)
-        return self._plan.nbytes()
+        return sum(p.nbytes() for p in self._i3d_plans)
 
 
 def init_state_dict(spec: ModelSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
