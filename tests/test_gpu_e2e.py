@@ -190,6 +190,30 @@ def test_chunking_and_streams_do_not_change_results(gpu):
         del m
 
 
+@pytest.mark.parametrize("name,B,T", [("resnet50_bilstm", 5, 16), ("twostream_transformer", 3, 32)])
+def test_heads_per_chunk_do_not_change_results(gpu, name, B, T):
+    """The temporal encoder + head run chunk by chunk on the chunks' streams (opt-in; chunks of one and of two clips,
+    a ragged last chunk) against one head over the whole batch after the backbone: same logits, forward and
+    classify_clip."""
+    from video_asl_recognition_amd import AslClipModel
+    clips = O.make_clips(B, T, 224, 12).cuda()
+    kp = O.make_keypoints(B, T, 13).cuda() if name.startswith("twostream") else None
+    m0 = AslClipModel(name, seed=4, chunk_heads=False)
+    ref = m0(clips, kp).clone()
+    frames = O.make_frames(B, T, 60, 80, 3).cuda()
+    ridx, rprob = m0.classify_clip(frames, kp, topk=3)
+    assert bool(torch.isfinite(ref).all()) and float((ref[0] - ref[1]).abs().max()) > 0
+    for chunk, streams in ((T, 2), (2 * T, 2), (2 * T, 1), (T + 5, 3)):
+        m = AslClipModel(name, seed=4, frames_per_chunk=chunk, streams=streams, chunk_heads=True)
+        assert m._heads_per_chunk()
+        for _ in range(2):                                  # the second call reuses plans, streams and freed buffers
+            torch.testing.assert_close(m(clips, kp), ref, rtol=1e-5, atol=1e-5)
+        idx, prob = m.classify_clip(frames, kp, topk=3)
+        assert torch.equal(idx, ridx)
+        torch.testing.assert_close(prob, rprob, rtol=1e-4, atol=1e-6)
+        del m
+
+
 def test_i3d_streams_and_chunk_pairs_do_not_change_results(gpu):
     """The 3-D backbone on one stream, with its Inception branches on three streams, and with chunks paired side by
     side on six streams (one-clip chunks: clips 0 and 1 together, clip 2 alone) gives the same logits bit for bit."""

@@ -77,7 +77,8 @@ class _BufPool:
 
 class AslClipModel:
     def __init__(self, spec, device: str = "cuda", frames_per_chunk: Optional[int] = None, seed: Optional[int] = None,
-                 streams: int = 2, s2d_entry: Optional[bool] = None, parity_mode: Optional[bool] = None):
+                 streams: int = 2, s2d_entry: Optional[bool] = None, parity_mode: Optional[bool] = None,
+                 chunk_heads: Optional[bool] = None):
         self.spec: ModelSpec = SPECS[spec] if isinstance(spec, str) else spec
         if not torch.cuda.is_available():
             raise RuntimeError("AslClipModel needs an MI355X (no GPU visible); there is no CPU path")
@@ -116,6 +117,12 @@ class AslClipModel:
         # ResNet stem straight from the bf16 clip tensor (no packed, halo'd copy of the input): ASL_PLANAR_STEM=0 goes
         # back to pack + packed-input stem (uint8 frames always take that road: preprocess writes the packed form)
         self.planar_stem = os.environ.get("ASL_PLANAR_STEM", "1") != "0"
+        # BiLSTM / transformer heads per chunk of whole clips, on the chunk's stream, under the other stream's backbone
+        # launches instead of one head over the whole batch after the backbone.  Opt-in (argument, or ASL_CHUNK_HEADS=1):
+        # measured no faster -- ResNet-50 + BiLSTM 16 x 64 17.65 against 16.39 ms (the recurrence's 128 short launches
+        # per chunk sit in front of the stream's next chunk), two-stream transformer 8 x 128 4.23 ms either way
+        self.chunk_heads = (os.environ.get("ASL_CHUNK_HEADS", "0") == "1") if chunk_heads is None else bool(chunk_heads)
+        self._keep_heads = None
         self._w: Dict[str, PackedConv] = {}
         self._fc_w = self._fc_b = None
         self._temporal = None
@@ -331,9 +338,14 @@ class AslClipModel:
         return cache[g]
 
     # ------------------------------------------------------------------ backbone
-    def _run_backbone(self, n_total: int, fill_x0, want_bf16: bool):
+    def _run_backbone(self, n_total: int, fill_x0, want_bf16: bool, chunk_head=None, T: int = 1):
         """fill_x0(op, c0, n, x0_ptr, in_halo) turns `op` (an L.Op) into the launch that writes frames
         [c0, c0+n) into the packed stem input at x0_ptr.
+
+        chunk_head(feats, feats_b, c0, n, stream), when given, is called once per chunk right after the chunk's
+        launches have been issued, with that chunk's stream current: chunks then hold whole clips of T frames, and a
+        chunk's temporal encoder runs on its own stream under the other streams' backbone launches instead of after
+        the whole batch.
 
         Chunks alternate between `self.streams` HIP streams (each with its own workspace), so one
         chunk's kernels fill the CUs another chunk's kernel leaves idle in its last, partial round of
@@ -354,6 +366,8 @@ class AslClipModel:
         feats_b = torch.empty(n_total, ld_b, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
         nstreams = max(1, min(self.streams, (n_total + self.frames_per_chunk - 1) // self.frames_per_chunk))
         step = min(self.frames_per_chunk, (n_total + nstreams - 1) // nstreams)
+        if chunk_head is not None:
+            step = (step + T - 1) // T * T              # whole clips per chunk
         plans = self._get_plans(step, nstreams)
         main = torch.cuda.current_stream()
         side = self._side_streams(nstreams)
@@ -397,6 +411,12 @@ class AslClipModel:
                 avg.ptr[2] = (bbase + c0 * ld_b * 2) if (feats_b is not None and not pm) else None
                 avg.i[5], avg.i[6] = ld_b, lo_off
             L.run_ops(arr, len(arr), sarr, nstreams, "backbone")
+            if chunk_head is not None:
+                for j in range(g):
+                    c0 = starts[g0 + j]
+                    s_ = side[j] if nstreams > 1 else main
+                    with torch.cuda.stream(s_):
+                        chunk_head(feats, feats_b, c0, min(step, n_total - c0), C.c_void_p(s_.cuda_stream))
         if nstreams > 1:
             for s_ in side:
                 main.wait_stream(s_)
@@ -420,7 +440,30 @@ class AslClipModel:
             self._groups = {}
         return self._plan
 
-    def frame_features(self, clips: torch.Tensor, want_bf16: bool = False):
+    def _heads_per_chunk(self) -> bool:
+        """BiLSTM / transformer heads run chunk by chunk on the chunks' streams (see _run_backbone); parity mode folds
+        its feature halves after the whole batch and keeps the one-head form."""
+        return self.chunk_heads and self.spec.temporal not in ("mean", "i3d") and not self.parity_mode
+
+    def _forward_chunk_heads(self, B: int, T: int, keypoints, run):
+        """run(chunk_head, T) drives the backbone; each chunk's clips go through the temporal encoder and head on the
+        chunk's stream and land in their rows of the batch's logits."""
+        logits = torch.empty(B, self.spec.num_classes, dtype=torch.float32, device=self.device)
+        if self.spec.keypoints and keypoints is not None:
+            keypoints = keypoints.to(self.device)
+        keep = []
+
+        def chunk_head(feats, feats_b, c0, n, stream):
+            b0, nb = c0 // T, n // T
+            kp = None if keypoints is None else keypoints[b0:b0 + nb]
+            out = self._temporal(feats[c0:c0 + n], feats_b[c0:c0 + n], feats_b.shape[1], nb, T, kp, stream)
+            logits[b0:b0 + nb].copy_(out)               # on the chunk's stream (current here)
+            keep.append((out, self._temporal._keep))
+        feats, feats_b = run(chunk_head, T)
+        self._keep_heads = (keep, feats, feats_b)       # asynchronous launches: buffers live until the next call
+        return logits
+
+    def frame_features(self, clips: torch.Tensor, want_bf16: bool = False, chunk_head=None, T: int = 1):
         """clips [B,T,3,S,S] -> per-frame features fp32 [B*T, F] (and their bf16 copy)."""
         clips = self._check_clips(clips)
         B, T, _, S, _ = clips.shape
@@ -438,7 +481,7 @@ class AslClipModel:
             op.kind = L.OP_PACK_CLIPS
             op.ptr[0], op.ptr[1] = base + c0 * 3 * S * S * esz, x0_ptr
             op.i[0], op.i[1], op.i[2], op.i[3] = in_f32, n, S, in_halo
-        return self._run_backbone(B * T, fill, want_bf16)
+        return self._run_backbone(B * T, fill, want_bf16, chunk_head, T)
 
     def _check_clips(self, clips):
         if clips.dim() != 5 or clips.shape[2] != 3 or clips.shape[3] != clips.shape[4]:
@@ -552,6 +595,8 @@ class AslClipModel:
             return self._run_i3d(B, T, fill)
         if self.spec.keypoints and keypoints is None:
             raise ValueError(f"spec {self.spec.name} needs keypoints [B,T,21,2]")
+        if self._heads_per_chunk():
+            return self._forward_chunk_heads(B, T, keypoints, lambda ch, t: self.frame_features(clips, True, ch, t))
         feats, feats_b = self.frame_features(clips, want_bf16=self.spec.temporal != "mean")
         return self._head(feats, feats_b, B, T, keypoints)
 
@@ -586,6 +631,8 @@ class AslClipModel:
                 L.check(L.lib.asl_preprocess_u8(C.c_void_p(base + f0 * H0 * W0 * 3), n, H0, W0, S, 3, mean, std, dst,
                                                 None, stream), "preprocess")
             logits = self._run_i3d(B, T, fill3)
+        elif self._heads_per_chunk():
+            logits = self._forward_chunk_heads(B, T, keypoints, lambda ch, t: self._run_backbone(B * T, fill, True, ch, t))
         else:
             feats, feats_b = self._run_backbone(B * T, fill, self.spec.temporal != "mean")
             logits = self._head(feats, feats_b, B, T, keypoints)
