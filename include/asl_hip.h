@@ -246,6 +246,25 @@ typedef struct asl_conv3d_params {
 int asl_conv3d_ndhwc_bf16(const asl_conv3d_params* p, const void* x, const void* w,
                           const float* scale, const float* bias, void* y, asl_stream_t stream);
 
+/* The I3D stem: nn.Conv3d(3, 64, 7, stride 2, pad 3, bias=False) + BatchNorm3d(eval) + ReLU on packed RGB clips, as a
+ * kernel that keeps the input rows of a run of output pixels in LDS (each input element is staged once per depth tap
+ * instead of once per window).  x: packed [n][frames+6][size+6][size+6][4] bf16 (halo 3 on every axis, channel 3 zero:
+ * asl_pack_clips / asl_preprocess_u8 with halo 3 into the frames behind each clip's three leading zero planes);
+ * w packed [w_rows][49*32] with w[co][(kd*7 + kh)*32 + q*4 + c] (q == 7, c == 3 zero), as the gather-GEMM takes it;
+ * y: [n][frames/2 + 2*out_halo_d][size/2 + 2*out_halo][size/2 + 2*out_halo][64].  frames and size even; cout must be 64
+ * and every 512-pixel tile's input rows must fit 32 KiB (size <= 224 at 7x7x7 / 2), ASL_ENOTSUP otherwise -- the same
+ * request then runs through asl_gather_gemm_bf16. */
+typedef struct asl_stem3d_params {
+    int32_t n, frames, size;
+    int32_t cout;
+    int32_t out_halo_d, out_halo;
+    int32_t relu;
+    int32_t w_rows;
+} asl_stem3d_params;
+
+int asl_stem3d_bf16(const asl_stem3d_params* p, const void* x, const void* w,
+                    const float* scale, const float* bias, void* y, asl_stream_t stream);
+
 /* nn.Linear on bf16 rows: y[m][n] = act(scale[n] * sum_k x[m][k] w[n][k] + bias[n] (+ res)).
  * x bf16 [m][ldx] (k % 32 == 0, ldx >= k), w packed [w_rows][k], y bf16 or fp32 [m][ldy],
  * res bf16 or (res_f32) fp32 [m][ldres]. */

@@ -431,6 +431,61 @@ def test_conv3d_3x3x3(gpu, variant, n, d, h, w, cin, cout, ctot, coff):
     assert torch.equal(y1, yd), "two launches on the same input differ"
 
 
+# The I3D stem kernel (7x7x7 / stride 2 / pad 3 on packed RGB, input rows resident in LDS): one tile per frame with a
+# short tail, tiles cut mid-row (112- and 50-wide frames), several tiles per frame, output halos 0 / 1 / 2, one clip and
+# several, both BatchNorm scale signs
+@pytest.mark.parametrize("n,frames,size,ohd,oh", [(2, 8, 32, 0, 1), (1, 4, 224, 0, 1), (3, 2, 40, 1, 0), (1, 6, 100, 2, 2),
+                                                  (2, 16, 64, 0, 1)])
+def test_stem3d(gpu, n, frames, size, ohd, oh):
+    from video_asl_recognition_amd import _lib as L
+    g = torch.Generator().manual_seed(frames * 1000 + size)
+    x = _bf16(torch.randn(n, 3, frames, size, size, generator=g))
+    wt = _bf16(torch.randn(64, 3, 7, 7, 7, generator=g) * (2.0 / 1029) ** 0.5)
+    scale = torch.empty(64).uniform_(0.5, 1.5, generator=g) * (torch.arange(64) % 5 != 0).float().mul(2).sub(1)
+    bias = torch.empty(64).normal_(0, 0.3, generator=g)
+    ref = F.relu(F.conv3d(x, wt, None, 2, 3) * scale.view(1, -1, 1, 1, 1) + bias.view(1, -1, 1, 1, 1))
+    wp = torch.zeros(128, 7, 7, 8, 4)
+    wp[:64, :, :, :7, :3] = wt.permute(0, 2, 3, 4, 1)
+    wd = wp.reshape(128, 49 * 32).to(torch.bfloat16).contiguous().cuda()
+    xd = torch.zeros(n, frames + 6, size + 6, size + 6, 4, dtype=torch.bfloat16)
+    xd[:, 3:-3, 3:-3, 3:-3, :3] = x.permute(0, 2, 3, 4, 1).to(torch.bfloat16)
+    xd = xd.cuda()
+    d1, h1 = frames // 2, size // 2
+    yd = torch.full((n, d1 + 2 * ohd, h1 + 2 * oh, h1 + 2 * oh, 64), 5.0, dtype=torch.bfloat16, device="cuda")
+    p = L.Stem3dParams(n=n, frames=frames, size=size, cout=64, out_halo_d=ohd, out_halo=oh, relu=1, w_rows=128)
+    sc, bi = scale.cuda(), bias.cuda()
+    args = (C.byref(p), _p(xd), _p(wd), _p(sc), _p(bi), _p(yd), None)
+    L.check(L.lib.asl_stem3d_bf16(*args), "stem3d")
+    torch.cuda.synchronize()
+    inner = yd[:, ohd:ohd + d1, oh:oh + h1, oh:oh + h1]
+    _assert_bf16_close(inner.float().cpu().permute(0, 4, 1, 2, 3), ref)
+    mask = torch.ones_like(yd, dtype=torch.bool)
+    mask[:, ohd:ohd + d1, oh:oh + h1, oh:oh + h1] = False
+    assert bool((yd[mask] == 5.0).all()), "halo was written"
+    y1 = yd.clone()
+    L.check(L.lib.asl_stem3d_bf16(*args), "stem3d")
+    torch.cuda.synchronize()
+    assert torch.equal(y1, yd), "two launches on the same input differ"
+
+
+def test_stem3d_rejects(gpu):
+    from video_asl_recognition_amd import _lib as L
+    x = torch.zeros(1, 10, 70, 70, 4, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(128, 49 * 32, dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(1, 2, 34, 34, 64, dtype=torch.bfloat16, device="cuda")
+    ok = dict(n=1, frames=4, size=64, cout=64, out_halo_d=0, out_halo=1, relu=1, w_rows=128)
+
+    def rc(**kw):
+        p = L.Stem3dParams(**{**ok, **kw})
+        return L.lib.asl_stem3d_bf16(C.byref(p), _p(x), _p(w), None, None, _p(y), None)
+    assert rc() == 0
+    assert rc(frames=3) == L.ASL_EINVAL and rc(size=63) == L.ASL_EINVAL and rc(n=0) == L.ASL_EINVAL
+    assert rc(w_rows=64) == L.ASL_EINVAL and rc(relu=2) == L.ASL_EINVAL
+    assert rc(cout=32) == L.ASL_ENOTSUP
+    assert rc(size=512) == L.ASL_ENOTSUP                 # a 512-pixel tile's input rows exceed a patch buffer: nothing is launched
+    torch.cuda.synchronize()
+
+
 def test_conv3d_forced_large_tile_kernel_refuses_what_it_cannot_run(gpu):
     from video_asl_recognition_amd import _lib as L
     x = torch.zeros(1, 4, 6, 6, 32, dtype=torch.bfloat16, device="cuda")

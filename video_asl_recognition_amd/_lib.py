@@ -61,6 +61,10 @@ class Conv3dParams(C.Structure):
         "pad_d", "pad", "out_halo_d", "out_halo", "out_ctot", "out_coff", "relu", "w_rows", "variant")]
 
 
+class Stem3dParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n", "frames", "size", "cout", "out_halo_d", "out_halo", "relu", "w_rows")]
+
+
 class LinearParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("m", "n", "k", "ldx", "ldy", "ldres", "relu", "out_f32", "res_f32", "w_rows")]
 
@@ -114,6 +118,7 @@ _PROTOS = {
     "asl_stem_conv_bf16": ([C.POINTER(StemParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_stem_pool_bf16": ([C.POINTER(StemPoolParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_conv3d_ndhwc_bf16": ([C.POINTER(Conv3dParams), _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_stem3d_bf16": ([C.POINTER(Stem3dParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_linear_bf16": ([C.POINTER(LinearParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_pack_clips": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
     "asl_preprocess_u8": ([_P, _I, _I, _I, _I, _I, _F3, _F3, _P, _P, _P], C.c_int),

@@ -4,6 +4,7 @@ of the block's concatenated output directly, and 3-D max-pools read the zero hal
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List
 
 import torch
@@ -138,7 +139,20 @@ class I3dPlan:
         g.relu, g.out_f32, g.res_f32, g.w_rows = 1, 0, 0, pc.w_rows
         sargs = (_ptr(self.x0), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), None, _ptr(a1.t))
 
+        # the LDS-resident-patch stem kernel takes the same tensors; the gather-GEMM form above is the fallback for sizes
+        # whose tiles do not fit it, and the ASL_I3D_GATHER_STEM=1 A/B switch
+        sp = L.Stem3dParams(n=0, frames=T, size=S, cout=64, out_halo_d=a1.hd, out_halo=a1.hh, relu=1, w_rows=pc.w_rows)
+        s3args = (_ptr(self.x0), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(a1.t))
+        use_gather = [os.environ.get("ASL_I3D_GATHER_STEM", "0") == "1" or T % 2 == 1]
+
         def stem(n, stream, g=g, sargs=sargs, keep=(a1, pc)):
+            if not use_gather[0]:
+                sp.n = n
+                rc = L.lib.asl_stem3d_bf16(C.byref(sp), *s3args, stream)
+                if rc != L.ASL_ENOTSUP:
+                    L.check(rc, "i3d stem")
+                    return
+                use_gather[0] = True
             g.nb = n
             g.x_elems = n * g.in_.sn
             g.y_elems = n * g.out.sn
