@@ -289,6 +289,12 @@ int asl_linear_bf16(const asl_linear_params* p, const void* x, const void* w,
 int asl_pack_clips(const void* clips, int in_f32, int n, int s, int halo, void* y,
                    asl_stream_t stream);
 
+/* The same for a 3-D backbone: clips [n_clips][frames][3][s][s] -> y [n_clips][frames + 2*halo_d][s+2*halo][s+2*halo][4] in
+ * ONE launch, frame f of a clip into plane halo_d + f.  The 2*halo_d halo planes of every clip are not written (they must
+ * already be zero); within a written plane the halo and channel 3 are zeroed as above. */
+int asl_pack_clips_3d(const void* clips, int in_f32, int n_clips, int frames, int s, int halo, int halo_d,
+                      void* y, asl_stream_t stream);
+
 /* F.interpolate(bilinear, align_corners=False, antialias=False) + /255 + (x-mean)/std:
  * frames uint8 [n][h0][w0][3]  ->  packed first-layer input [n][s+2*halo][s+2*halo][4] bf16
  * (as above).  If clips_f32 != NULL the normalised fp32 [n][3][s][s] tensor is written as well. */

@@ -642,6 +642,26 @@ def test_pack_clips_bf16_layout_exact(gpu, s, halo):
         assert torch.equal(x0.float().cpu(), want)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pack_clips_3d_matches_per_clip_packing(gpu, dtype):
+    """One launch for a batch of clips (frames of clip b behind the zero halo planes of its own depth axis) against
+    asl_pack_clips clip by clip; halo planes are left as they were."""
+    from video_asl_recognition_amd import _lib as L
+    nc, T, s, halo, hd = 3, 5, 20, 3, 3
+    clips = torch.randn(nc * T, 3, s, s, device="cuda").to(dtype)
+    sp = s + 2 * halo
+    one = torch.full((nc, T + 2 * hd, sp, sp, 4), 7.0, dtype=torch.bfloat16, device="cuda")
+    per = one.clone()
+    L.check(L.lib.asl_pack_clips_3d(_p(clips), int(dtype == torch.float32), nc, T, s, halo, hd, _p(one), None), "pack3d")
+    for b in range(nc):
+        L.check(L.lib.asl_pack_clips(_p(clips[b * T:]), int(dtype == torch.float32), T, s, halo, _p(per[b, hd:]), None), "pack")
+    torch.cuda.synchronize()
+    assert torch.equal(one, per)
+    assert bool((one[:, :hd] == 7.0).all()) and bool((one[:, hd + T:] == 7.0).all())
+    assert bool((one[:, hd:hd + T, :, :, 3] == 0).all()) and float(one[:, hd:hd + T, halo:-halo, halo:-halo, :3].float().abs().sum()) > 0
+    assert L.lib.asl_pack_clips_3d(_p(clips), 0, nc, T, 21, halo, hd, _p(one), None) == L.ASL_EINVAL
+
+
 def test_maxpool_exact(gpu):
     from video_asl_recognition_amd import _lib as L
     x = _bf16(torch.rand(2, 64, 30, 22) * 4)

@@ -11,9 +11,11 @@ namespace asl_detail {
 // ---------------------------------------------------------------------------------------
 // clips [n][3][s][s] -> packed [n][s+2*halo][s+2*halo][4] bf16; one lane per 2 output pixels (16 B)
 // ---------------------------------------------------------------------------------------
+// T > 0: the frames are clips of T frames and y is [clips][T + 2*hd][sp][sp][4]; frame f of a clip goes to plane hd + f
+// (the 2*hd halo planes of every clip are not touched)
 template <bool F32>
 __global__ __launch_bounds__(256) void pack_clips_kernel(const void* __restrict__ clips, int n, int s,
-                                                         int kHalo0, short* __restrict__ y) {
+                                                         int kHalo0, short* __restrict__ y, int T, int hd) {
     const int sp = s + 2 * kHalo0;          // even: s is even
     const int pairs_per_row = sp / 2;
     const long long total = (long long)n * sp * pairs_per_row;
@@ -39,7 +41,8 @@ __global__ __launch_bounds__(256) void pack_clips_kernel(const void* __restrict_
                 }
             }
         }
-        *(bf16x8*)(y + 8 * i) = o;
+        const long long dimg = T ? img / T * (T + 2 * hd) + hd + img % T : img;
+        *(bf16x8*)(y + 8 * ((dimg * sp + py) * pairs_per_row + px / 2)) = o;
     }
 }
 
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void pack_clips_kernel(const void* __restrict_
 // so the sources are only 2-byte aligned) and funnel-shifts them into place; 9 loads and 4 stores per 64 B
 // against 24 two-byte loads for the same bytes in the generic kernel.
 __global__ __launch_bounds__(256) void pack_clips_bf16x8_kernel(const short* __restrict__ clips, int n, int s, int kHalo0,
-                                                                short* __restrict__ y) {
+                                                                short* __restrict__ y, int T, int hd) {
     const int sp = s + 2 * kHalo0;
     const int groups = (sp + 7) >> 3;
     const long long total = (long long)n * sp * groups;
@@ -78,7 +81,8 @@ __global__ __launch_bounds__(256) void pack_clips_bf16x8_kernel(const short* __r
                 v[c][1] = shr ? (w[1] >> shr) | (w[2] << (64 - shr)) : w[1];
             }
         }
-        short* dst = y + (((img * sp + py) * sp) + px0) * 4;
+        const long long dimg = T ? img / T * (T + 2 * hd) + hd + img % T : img;
+        short* dst = y + (((dimg * sp + py) * sp) + px0) * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                    // two pixels per 16-byte store
             if (px0 + 2 * q < sp) {
@@ -533,16 +537,26 @@ int grid_for(long long total) {
 }  // namespace asl_detail
 using namespace asl_detail;
 
-extern "C" int asl_pack_clips(const void* clips, int in_f32, int n, int s, int halo, void* y, asl_stream_t stream) {
-    if (!clips || !y || n <= 0 || s <= 0 || (s & 1) || halo < 0 || ((uintptr_t)y & 15)) return ASL_EINVAL;
+static int pack_clips_launch(const void* clips, int in_f32, int n, int s, int halo, void* y, int T, int hd, hipStream_t st) {
     const long long total = (long long)n * (s + 2 * halo) * ((s + 2 * halo) / 2);
-    hipStream_t st = (hipStream_t)stream;
-    if (in_f32) hipLaunchKernelGGL(pack_clips_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, halo, (short*)y);
+    if (in_f32) hipLaunchKernelGGL(pack_clips_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, halo, (short*)y, T, hd);
     else if ((s & 3) == 0 && ((uintptr_t)clips & 7) == 0) {
         const long long items = (long long)n * (s + 2 * halo) * ((s + 2 * halo + 7) / 8);
-        hipLaunchKernelGGL(pack_clips_bf16x8_kernel, dim3(grid_for(items)), dim3(256), 0, st, (const short*)clips, n, s, halo, (short*)y);
-    } else hipLaunchKernelGGL(pack_clips_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, halo, (short*)y);
+        hipLaunchKernelGGL(pack_clips_bf16x8_kernel, dim3(grid_for(items)), dim3(256), 0, st, (const short*)clips, n, s, halo, (short*)y, T, hd);
+    } else hipLaunchKernelGGL(pack_clips_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, clips, n, s, halo, (short*)y, T, hd);
     return (int)hipGetLastError();
+}
+
+extern "C" int asl_pack_clips(const void* clips, int in_f32, int n, int s, int halo, void* y, asl_stream_t stream) {
+    if (!clips || !y || n <= 0 || s <= 0 || (s & 1) || halo < 0 || ((uintptr_t)y & 15)) return ASL_EINVAL;
+    return pack_clips_launch(clips, in_f32, n, s, halo, y, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int asl_pack_clips_3d(const void* clips, int in_f32, int n_clips, int frames, int s, int halo, int halo_d, void* y,
+                                 asl_stream_t stream) {
+    if (!clips || !y || n_clips <= 0 || frames <= 0 || s <= 0 || (s & 1) || halo < 0 || halo_d < 0 || ((uintptr_t)y & 15)) return ASL_EINVAL;
+    if ((long long)n_clips * frames > 0x7fffffffLL) return ASL_EINVAL;
+    return pack_clips_launch(clips, in_f32, n_clips * frames, s, halo, y, frames, halo_d, (hipStream_t)stream);
 }
 
 extern "C" int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, int s, int halo, const float mean[3],

@@ -507,9 +507,10 @@ class AslClipModel:
         return self._temporal(feats, feats_b, feats_b.shape[1], B, T, keypoints, stream)
 
     # ------------------------------------------------------------------ I3D
-    def _run_i3d(self, B: int, T: int, fill_frames):
+    def _run_i3d(self, B: int, T: int, fill_frames, fill_chunk=None):
         """fill_frames(f0, n, dst_ptr, stream) writes frames [f0, f0+n) (flattened over B*T) as packed
-        [n][S+6][S+6][4] at dst_ptr.  Clips run through the 3-D backbone a chunk (16 clips of 64 frames) at a time, the
+        [n][S+6][S+6][4] at dst_ptr; fill_chunk(b0, n, x0_ptr, stream), when given, packs clips [b0, b0+n) into a plan's
+        whole input tensor with one launch instead.  Clips run through the 3-D backbone a chunk (16 clips of 64 frames) at a time, the
         Inception branches of a chunk on three streams (I3dPlan.sched).  A batch of two or more full chunks runs them in
         pairs side by side, each on a main stream of its own plus two branch streams, launches issued alternately: one
         chunk's memory-bound pools then run under the other's convolutions (32 x 64: 12.6 -> 12.0 ms; with chunks smaller
@@ -545,6 +546,9 @@ class AslClipModel:
                 groups[1][0].wait_event(ev[6])
             for plan, (gm, _), (b0, n) in act:
                 h = C.c_void_p(gm.cuda_stream)
+                if fill_chunk is not None:
+                    fill_chunk(b0, n, C.c_void_p(plan.x0.data_ptr()), h)
+                    continue
                 for b in range(n):  # frames of clip b sit behind 3 zero halo frames of its own padded depth axis
                     dst = plan.x0.data_ptr() + ((b * (T + 6) + 3) * plane) * 2
                     fill_frames((b0 + b) * T, T, C.c_void_p(dst), h)
@@ -592,7 +596,10 @@ class AslClipModel:
             def fill(f0, n, dst, stream):
                 L.check(L.lib.asl_pack_clips(C.c_void_p(base + f0 * 3 * S * S * esz), in_f32, n, S, 3, dst, stream),
                         "pack_clips")
-            return self._run_i3d(B, T, fill)
+            def fill_chunk(b0, n, dst, stream):
+                L.check(L.lib.asl_pack_clips_3d(C.c_void_p(base + b0 * T * 3 * S * S * esz), in_f32, n, T, S, 3, 3, dst, stream),
+                        "pack_clips_3d")
+            return self._run_i3d(B, T, fill, fill_chunk)
         if self.spec.keypoints and keypoints is None:
             raise ValueError(f"spec {self.spec.name} needs keypoints [B,T,21,2]")
         if self._heads_per_chunk():
