@@ -125,7 +125,14 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
     const char* wbase = a.w + 2LL * (tn * S::TN) * a.wk;
     const unsigned wrec = (unsigned)(a.w_bytes - 2LL * (tn * S::TN) * a.wk);
     __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wrec, 0x00020000);
-    constexpr unsigned kOob = 0x80000000u;              // beyond num_records: the DMA writes zeros
+    // Pieces past the end -- of the tile's patch, of the last half-chunk, of the last weight stage -- are issued like any
+    // other (every wave issues the same number of pieces per step: the waits below count them) but must not touch
+    // memory: the scalar offset of a buffer access is outside the descriptor's range check, only the per-lane offset is
+    // inside it.  Their per-lane offset gets bit 31 set (beyond num_records: the DMA writes zeros) by OR-ing a
+    // wave-uniform mask, which costs no register across the loop (a select against a constant did: in the 3-D instance
+    // the two DMA offsets ended up in scratch and were reloaded at the top of every iteration -- one more operation on
+    // the counter the waits count, with an s_waitcnt vmcnt(0) in front of its first use).
+    constexpr unsigned kOob = 0x80000000u;
 
     // Patch image in LDS: piece j (1 KiB) holds patch pixels 16j..16j+15 chunk-major, byte (p, c) at
     // (p >> 4) * 1024 + c * 256 + (p & 15) * 16 (c = 16-byte chunk of the pixel's 64).  The 16-byte slot within
@@ -134,12 +141,12 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
     const unsigned pvoff = (unsigned)((lane & 15) * pix_bytes + (lane >> 4) * 16);
     auto dma_patch_piece = [&](int q, int k) {          // piece (wave + 8k) of pair q = (half-chunk q / KD, depth tap q % KD)
         const int j = wave + 8 * k;
-        const bool live = q < nq && 16 * j < NP;        // else: zeros, into the piece itself or the spare last piece
-        const int jd = j < S::PIECES ? j : S::PIECES - 1;
+        const unsigned dead = __builtin_amdgcn_readfirstlane(q < nq && 16 * j < NP ? 0u : kOob);
+        const int jd = j < S::PIECES ? j : S::PIECES - 1;    // surplus pieces of the last round: into the spare last piece
         const int hc = KD == 3 ? q / 3 : q, kt = q - hc * KD;
         const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(16LL * j * pix_bytes + hc * 64) + (unsigned)kt * plane_bytes);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(patches + (q & 1) * S::PATCH_BYTES + jd * 1024),
-                                                 16, live ? pvoff : kOob, live ? so : 0u, 0, 0);
+                                                 16, pvoff | dead, dead ? 0u : so, 0, 0);
     };
     // weight piece q = wave * WPW + i covers tile rows 16q..16q+15 (64 B each); chunk swizzle (row & 8) ? 3 : 0
     unsigned wvoff[WPW];
@@ -149,15 +156,15 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         wvoff[i] = (unsigned)(2 * row * a.wk + 16 * ((lane & 3) ^ ((row & 8) ? 3 : 0)));
     }
     auto dma_weights = [&](int s, int slot) {           // stage s = q * 9 + tap -> ring slot s % RING
-        const bool live = s < nsteps;
+        const unsigned dead = __builtin_amdgcn_readfirstlane(s < nsteps ? 0u : kOob);
         const int q = s / 9, tap = s - 9 * q;
         const int hc = KD == 3 ? q / 3 : q, kt = q - hc * KD;
-        const unsigned so = __builtin_amdgcn_readfirstlane(live ? (unsigned)(2 * ((kt * 9 + tap) * a.C + hc * 32)) : 0u);
+        const unsigned so = __builtin_amdgcn_readfirstlane(dead ? 0u : (unsigned)(2 * ((kt * 9 + tap) * a.C + hc * 32)));
         char* dst = ring + slot * WST + wave * (WPW * 1024);
 #pragma unroll
         for (int i = 0; i < WPW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
-                                                     live ? wvoff[i] : kOob, so, 0, 0);
+                                                     wvoff[i] | dead, so, 0, 0);
     };
 
     // ---- per-lane fragment geometry ----------------------------------------------------------
@@ -181,11 +188,12 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
     // 2h+1 are eight CONSECUTIVE output channels of its pixel (MFMA row r of fragment j is channel
     // (j>>1)*32 + (r>>2)*8 + (j&1)*4 + (r&3) of the wave's 64): the epilogue stores 16 bytes per lane straight
     // from registers.  The 64-byte-row swizzle is conflict-free for this order too.
-    int wrd[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int row = wc * 64 + (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);
-        wrd[j] = row * 64 + ((fq ^ ((row & 8) ? 3 : 0)) << 4);
+    // (fragment j reads row (j >> 1) * 32 + (j & 1) * 4 + row0; bit 3 of the row, which picks the swizzle, is the same for
+    // all four, so they are constant offsets from ONE address register)
+    int wrd0;
+    {
+        const int row0 = wc * 64 + (fr >> 2) * 8 + (fr & 3);
+        wrd0 = row0 * 64 + ((fq ^ ((row0 & 8) ? 3 : 0)) << 4);
     }
 
     f32x4 acc[FM][FN];
@@ -227,10 +235,10 @@ __global__ __launch_bounds__(512, PpShape<FM_>::WAVES_PER_EU) void conv3x3_pp_ke
         dma_weights(s + DIST, slot_next);
         const int o = (tap / 3) * a.Wp + tap % 3;       // tap pixel relative to the top-left one
         const int so = __builtin_amdgcn_readfirstlane((((o >> 4) << 10) | ((o & 15) << 4)) + pboff);
-        const char* wb = ring + slot * WST;
+        const char* wb = ring + slot * WST + wrd0;
         bf16x8 xf[FM], wf[FN];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(wb + wrd[j]);
+        for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(wb + (j >> 1) * 2048 + (j & 1) * 256);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             // two vector instructions per address (the K loop is bound by vector issue, not by the MFMA pipe).
