@@ -68,6 +68,13 @@ def pack_i3d_weights(spec: ModelSpec, sd, dev) -> Dict[str, PackedConv]:
                               (7, 7, 7), p.shape[0])
     unit("conv_2b")
     unit("conv_2c")
+    # conv_2c (64 -> 192 at 56 x 56) runs on the gather-GEMM, whose channel tiles are 128 or 64 wide: as one launch its
+    # second tile multiplies 64 rows of zero padding; as a 128-wide and a 64-wide launch into the two channel slices of
+    # the output it does not (ASL_I3D_SPLIT_2C=0 keeps the single launch)
+    s2c, b2c = bn_scale_bias(sd, "backbone.conv_2c.bn", 1e-3, dev)
+    w2c = sd["backbone.conv_2c.conv.weight"]
+    for tag, lo, hi in (("lo", 0, 128), ("hi", 128, 192)):
+        w["conv_2c." + tag] = pack_conv(w2c[lo:hi], dev, scale=s2c[lo:hi].contiguous(), bias=b2c[lo:hi].contiguous())
     cin = 192
     for name, wd in I3D_MIXED:
         if wd is None:
@@ -166,7 +173,11 @@ class I3dPlan:
         conv(w["conv_2b"], a2, a3)
         pool.put(a2)
         a4 = pool.get(a3.d, a3.h, a3.w, 192, 0, 1)
-        conv(w["conv_2c"], a3, a4)
+        if os.environ.get("ASL_I3D_SPLIT_2C", "1") == "1" and w["conv_2c"].cout == 192:
+            conv(w["conv_2c.lo"], a3, a4, 0)
+            conv(w["conv_2c.hi"], a3, a4, 128)
+        else:
+            conv(w["conv_2c"], a3, a4)
         pool.put(a3)
         x = pool.get(a4.d, a4.h // 2, a4.w // 2, 192, 1, 1)
         maxpool(a4, x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
