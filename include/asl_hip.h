@@ -265,6 +265,26 @@ typedef struct asl_stem3d_params {
 int asl_stem3d_bf16(const asl_stem3d_params* p, const void* x, const void* w,
                     const float* scale, const float* bias, void* y, asl_stream_t stream);
 
+/* The exit of a ResNet bottleneck whose shortcut is a projection, in one launch:
+ *     y = relu( bn3(conv3(t)) + bn_ds(conv_ds(x)) ),   conv3: nn.Conv2d(cin, cout, 1), conv_ds: nn.Conv2d(cin2, cout, 1, stride2)
+ * computed as act(scale * (W3 . t + pre_scale * (Wds . x)) + bias) with scale = bn3's scale, pre_scale = bn_ds's scale /
+ * bn3's scale and bias = the two BatchNorm biases added (packing.pack_dual1x1): the shortcut tensor never reaches HBM.
+ * t: [n][h+2*in_halo][w+2*in_halo][cin]; x: [n][h*stride2+2*in2_halo][w*stride2+2*in2_halo][cin2];
+ * w packed [w_rows][cin2 + cin], the shortcut's columns first; cin and cin2 multiples of 64 (ASL_ENOTSUP for other
+ * multiples of 32); y as for asl_conv2d_nhwc_bf16. */
+typedef struct asl_dual1x1_params {
+    int32_t n, h, w;
+    int32_t cin, in_halo;
+    int32_t cin2, in2_halo, stride2;
+    int32_t cout, out_halo, out_ctot, out_coff;
+    int32_t relu;
+    int32_t w_rows;
+} asl_dual1x1_params;
+
+int asl_conv1x1_dual_bf16(const asl_dual1x1_params* p, const void* t, const void* x, const void* w,
+                          const float* scale, const float* bias, const float* pre_scale, void* y,
+                          asl_stream_t stream);
+
 /* nn.Linear on bf16 rows: y[m][n] = act(scale[n] * sum_k x[m][k] w[n][k] + bias[n] (+ res)).
  * x bf16 [m][ldx] (k % 32 == 0, ldx >= k), w packed [w_rows][k], y bf16 or fp32 [m][ldy],
  * res bf16 or (res_f32) fp32 [m][ldres]. */
@@ -439,6 +459,7 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
  *   ASL_OP_BASIC_BLOCK   asl_block_params*       x, w1, scale1, bias1, w2, scale2, bias2, y
  *   ASL_OP_BLOCK_ENTRY   asl_entry_params*       x2, w, scale, bias, w_ds, scale_ds, bias_ds, y, y_ds
  *   ASL_OP_MAXPOOL_SPLIT NULL                    x, y                                    n, h, w, c, in_halo, out_halo
+ *   ASL_OP_CONV1X1_DUAL  asl_dual1x1_params*     t, x, w, scale, bias, pre_scale, y
  *
  * Returns ASL_OK, or the first failing op's return code with its index in *failed (if failed != NULL); ops
  * before it have been issued, ops after it have not.  ASL_EINVAL for an unknown kind, a stream index outside
@@ -446,7 +467,8 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
 enum {
     ASL_OP_NOP = 0, ASL_OP_CONV2D = 1, ASL_OP_STEM_CONV = 2, ASL_OP_STEM_POOL = 3, ASL_OP_CONV3D = 4, ASL_OP_LINEAR = 5,
     ASL_OP_MAXPOOL3D = 6, ASL_OP_MAXPOOL = 7, ASL_OP_AVGPOOL = 8, ASL_OP_PACK_CLIPS = 9, ASL_OP_PREPROCESS = 10,
-    ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12, ASL_OP_BASIC_BLOCK = 13, ASL_OP_BLOCK_ENTRY = 14, ASL_OP_MAXPOOL_SPLIT = 15
+    ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12, ASL_OP_BASIC_BLOCK = 13, ASL_OP_BLOCK_ENTRY = 14, ASL_OP_MAXPOOL_SPLIT = 15,
+    ASL_OP_CONV1X1_DUAL = 16
 };
 
 typedef struct asl_op {

@@ -111,6 +111,44 @@ def test_gather_gemm_conv_shapes(gpu, n, h, w, cin, cout, k, stride, pad, res, r
     _run_conv_case(n, h, w, cin, cout, k, stride, pad, res, relu, variant=L.CONV_GATHER)
 
 
+# Bottleneck exit + projected shortcut in one launch: stride-1 and stride-2 shortcuts, different halos on the two inputs,
+# a channel count that is not a whole 128-channel tile, a slice of a wider output, both signs of the BatchNorm scales
+@pytest.mark.parametrize("n,h,w,cin,cin2,cout,stride2,ih,ih2,oh_,ctot,coff", [
+    (3, 14, 14, 64, 128, 256, 2, 1, 1, 1, 256, 0), (2, 28, 28, 64, 64, 256, 1, 1, 1, 1, 256, 0),
+    (2, 7, 9, 128, 192, 200, 2, 0, 1, 0, 200, 0), (1, 5, 5, 256, 64, 128, 1, 1, 0, 2, 320, 64), (5, 7, 7, 512, 1024, 2048, 2, 1, 1, 1, 2048, 0)])
+def test_conv1x1_dual(gpu, n, h, w, cin, cin2, cout, stride2, ih, ih2, oh_, ctot, coff):
+    from video_asl_recognition_amd import _lib as L
+    from video_asl_recognition_amd.packing import pack_dual1x1
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    t = _bf16(torch.randn(n, cin, h, w, generator=g))
+    x = _bf16(torch.randn(n, cin2, h * stride2, w * stride2, generator=g))
+    w3 = _bf16(torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5)
+    wd = _bf16(torch.randn(cout, cin2, 1, 1, generator=g) * (2.0 / cin2) ** 0.5)
+    sgn = (torch.arange(cout) % 3 != 0).float().mul(2).sub(1)
+    s3 = torch.empty(cout).uniform_(0.2, 0.6, generator=g) * sgn
+    sd_ = torch.empty(cout).uniform_(0.5, 1.5, generator=g) * sgn.roll(1)
+    b3, bd = torch.empty(cout).normal_(0, 0.1, generator=g), torch.empty(cout).normal_(0, 0.1, generator=g)
+    v = lambda a: a.view(1, -1, 1, 1)
+    ref = F.relu(F.conv2d(t, w3) * v(s3) + v(b3) + F.conv2d(x, wd, stride=stride2) * v(sd_) + v(bd))
+    pc, pre = pack_dual1x1(w3, s3, b3, wd, sd_, bd, "cuda")
+    td = F.pad(t.permute(0, 2, 3, 1), (0, 0, ih, ih, ih, ih)).to(torch.bfloat16).contiguous().cuda()
+    xd = F.pad(x.permute(0, 2, 3, 1), (0, 0, ih2, ih2, ih2, ih2)).to(torch.bfloat16).contiguous().cuda()
+    yd = torch.full((n, h + 2 * oh_, w + 2 * oh_, ctot), 5.0, dtype=torch.bfloat16, device="cuda")
+    p = L.Dual1x1Params(n=n, h=h, w=w, cin=cin, in_halo=ih, cin2=cin2, in2_halo=ih2, stride2=stride2, cout=cout, out_halo=oh_,
+                        out_ctot=ctot, out_coff=coff, relu=1, w_rows=pc.w_rows)
+    args = (C.byref(p), _p(td), _p(xd), _p(pc.w), _p(pc.scale), _p(pc.bias), _p(pre), _p(yd), None)
+    L.check(L.lib.asl_conv1x1_dual_bf16(*args), "dual")
+    torch.cuda.synchronize()
+    got = yd[:, oh_:oh_ + h, oh_:oh_ + w, coff:coff + cout].float().cpu().permute(0, 3, 1, 2)
+    _assert_bf16_close(got, ref)
+    mask = torch.ones_like(yd, dtype=torch.bool)
+    mask[:, oh_:oh_ + h, oh_:oh_ + w, coff:coff + cout] = False
+    assert bool((yd[mask] == 5.0).all()), "something outside the output slice was written"
+    bad = L.Dual1x1Params(n=n, h=h, w=w, cin=cin + 32, in_halo=ih, cin2=cin2, in2_halo=ih2, stride2=stride2, cout=cout,
+                          out_halo=oh_, out_ctot=ctot, out_coff=coff, relu=1, w_rows=pc.w_rows)
+    assert L.lib.asl_conv1x1_dual_bf16(C.byref(bad), *args[1:]) == L.ASL_ENOTSUP
+
+
 def test_forced_variant_that_does_not_fit_is_refused(gpu):
     from video_asl_recognition_amd import _lib as L
     for variant in (L.CONV_C64, L.CONV_PP, L.CONV_WIDE):      # a 1x1 conv fits none of the 3x3 kernels

@@ -27,6 +27,10 @@ def describe(rec, n):
         macs = n * oh * ow * p.cout * p.cin * p.kh * p.kw
         byts = 2 * n * (p.h * p.w * p.cin + oh * ow * p.cout * (2 if p.res_ctot else 1))
         return f"{p.kh}x{p.kw}/{p.stride} {p.cin:4d}->{p.cout:4d} @{p.h}x{p.w}{' +res' if p.res_ctot else ''}", macs, byts
+    if kind == L.OP_CONV1X1_DUAL:
+        macs = n * p.h * p.w * p.cout * (p.cin + p.cin2)
+        byts = 2 * n * p.h * p.w * (p.cin + p.cin2 + p.cout)
+        return f"1x1 {p.cin:4d}->{p.cout:4d} @{p.h}x{p.w} + shortcut 1x1/{p.stride2} {p.cin2:4d}->{p.cout:4d}", macs, byts
     if kind == L.OP_BASIC_BLOCK:
         macs = 2 * n * p.h * p.w * 64 * 64 * 9
         return f"block 64 @{p.h}x{p.w}", macs, 2 * n * p.h * p.w * 64 * 2

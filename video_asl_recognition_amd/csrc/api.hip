@@ -219,6 +219,10 @@ extern "C" int asl_run_ops(const asl_op* ops, int count, const asl_stream_t* str
                                                  (const float*)p[3], p[4], (const float*)p[5], (const float*)p[6],
                                                  p[7], p[8], s);
                     break;
+                case ASL_OP_CONV1X1_DUAL:
+                    rc = asl_conv1x1_dual_bf16((const asl_dual1x1_params*)o.params, p[0], p[1], p[2], (const float*)p[3],
+                                               (const float*)p[4], (const float*)p[5], p[6], s);
+                    break;
                 default:
                     rc = ASL_EINVAL;
             }

@@ -34,7 +34,7 @@ __device__ __forceinline__ int swz(int row) {
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool SPLIT = false>
+template <int BM, int BN, int BK, int WGM, int WGN, bool SPLIT = false, bool DUAL = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub; the body uses device-only types
     constexpr int NW = WGM * WGN;
@@ -79,6 +79,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
     __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, wrec, 0x00020000);
 
     unsigned xvoff[X_PW], wvoff[W_PW];
+    unsigned xvoff2[DUAL ? X_PW : 1];   // DUAL: the same rows of the second activation operand
+    __amdgpu_buffer_rsrc_t xrs2 = xrs;
+    if constexpr (DUAL) {
+        const long long x2rem = a.x2_bytes - 2 * (long long)n0img * a.in2_sn;
+        xrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 + 2 * (long long)n0img * a.in2_sn), 0,
+                                                 (unsigned)(x2rem > 0x7fffffffLL ? 0x7fffffffLL : x2rem), 0x00020000);
+    }
 #pragma unroll
     for (int i = 0; i < X_PW; ++i) {
         const int row = (wave * X_PW + i) * RPI + lane / CPR;
@@ -91,8 +98,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
             const long long e = (long long)(n - n0img) * a.in_sn + (long long)d * a.in_sd +
                                 (long long)h * a.in_sh + (long long)w_ * a.in_sw + a.in_off0;
             xvoff[i] = (unsigned)(2 * e + 16 * chunk);
+            if constexpr (DUAL) {
+                const long long e2 = (long long)(n - n0img) * a.in2_sn + (long long)h * a.in2_sh + (long long)w_ * a.in2_sw + a.in2_off0;
+                xvoff2[i] = (unsigned)(2 * e2 + 16 * chunk);
+            }
         } else {
             xvoff[i] = 0x80000000u;     // beyond num_records: the DMA writes zeros
+            if constexpr (DUAL) xvoff2[i] = 0x80000000u;
         }
     }
 #pragma unroll
@@ -104,6 +116,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
 
     // ---- K-step state (scalar): tap (d,r,q) and channel chunk -----------------------------
     int st_c = 0, st_q = 0, st_r = 0, st_d = 0;
+    int st_i = 0;                            // DUAL: K steps issued so far
     unsigned st_xoff = 0, st_woff = 0;      // byte offsets for the NEXT stage() call
     auto stage = [&](int buf) {
         char* lx = smem + buf * BUF + wave * (X_PW * 1024);
@@ -112,6 +125,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
         // readfirstlane loop
         const unsigned xo = __builtin_amdgcn_readfirstlane(st_xoff);
         const unsigned wo = __builtin_amdgcn_readfirstlane(st_woff);
+        if constexpr (DUAL) {
+            if (st_i < a.nsteps2) {          // a step of the second operand: its channels st_i * BK .. of every row
+                const unsigned xo2 = __builtin_amdgcn_readfirstlane((unsigned)st_i * (unsigned)RB);
+#pragma unroll
+                for (int i = 0; i < X_PW; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs2, (__attribute__((address_space(3))) void*)(lx + i * 1024),
+                                                             16, xvoff2[i], xo2, 0, 0);
+#pragma unroll
+                for (int i = 0; i < W_PW; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(lw + i * 1024),
+                                                             16, wvoff[i], wo, 0, 0);
+                st_woff += RB;
+                ++st_i;
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < X_PW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(lx + i * 1024),
@@ -167,7 +196,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
     EpiState<FM, FN> est;
     epilogue_prepare<FM, FN, SPLIT>(est, g, m0 + wm * WTM, tn * BN + wn * WTN, lane);
 
-    const int nsteps = a.ntaps * a.ksteps_per_tap;
+    const int nsteps = a.ntaps * a.ksteps_per_tap + (DUAL ? a.nsteps2 : 0);
     stage(0);
     wait_vm0();
     __syncthreads();
@@ -188,6 +217,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         }
+        if constexpr (DUAL) {
+            if (s == a.nsteps2 - 1) {        // the second operand is done: its sum takes its own per-channel scale
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int ch = tn * BN + wn * WTN + j * 16 + fq * 4;
+                    const f32x4 r = ch + 3 < a.N ? *(const f32x4*)(a.pre_scale + ch) : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) acc[i][j] *= r;
+                }
+            }
+        }
         wait_vm0();
         __syncthreads();
         buf ^= 1;
@@ -200,7 +240,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gather_gemm_kernel(const GemmAr
 }
 
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool SPLIT = false>
+template <int BM, int BN, int BK, int WGM, int WGN, bool SPLIT = false, bool DUAL = false>
 int launch(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * BK * 2;
     static_assert(lds <= 65536, "tiles above 64 KiB of LDS need hipFuncSetAttribute");
@@ -209,7 +249,7 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     b.tiles_n = (a.N + BN - 1) / BN;
     const long long nblk = (long long)b.tiles_m * b.tiles_n;
     if (nblk > 0x7fffffffLL) return ASL_EINVAL;
-    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, BK, WGM, WGN, SPLIT>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), lds, stream, b);
+    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, BK, WGM, WGN, SPLIT, DUAL>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), lds, stream, b);
     return (int)hipGetLastError();
 }
 
@@ -365,4 +405,55 @@ extern "C" int asl_gather_gemm_bf16(const asl_gemm_params* p, const void* x, con
     a.ksteps_per_tap = p->ck / 32;
     if (p->cout <= 64) return launch<128, 64, 32, 2, 2>(a, s);
     return launch<128, 128, 32, 2, 4>(a, s);
+}
+
+// One launch for the last two GEMMs of a ResNet bottleneck whose shortcut is a projection:
+//     y = act( scale * ( W1 . t  +  pre_scale * ( W2 . x_strided ) ) + bias )
+// with t the 1x1 / stride 1 operand and x the 1x1 / stride `stride2` one.  The shortcut's K steps run first, the
+// accumulator is multiplied by pre_scale (fp32, one rounding), and the main branch accumulates on top: the shortcut
+// tensor is neither written nor read back.
+extern "C" int asl_conv1x1_dual_bf16(const asl_dual1x1_params* p, const void* t, const void* x, const void* w, const float* scale,
+                                     const float* bias, const float* pre_scale, void* y, asl_stream_t stream) {
+    if (!p || !t || !x || !w || !y || !pre_scale) return ASL_EINVAL;
+    if (p->n <= 0 || p->h <= 0 || p->w <= 0 || p->cin <= 0 || p->cin2 <= 0 || p->cout <= 0 || p->stride2 <= 0) return ASL_EINVAL;
+    if ((p->cin & 63) || (p->cin2 & 63) || (p->cout & 7)) return (p->cin & 31) || (p->cin2 & 31) || (p->cout & 7) ? ASL_EINVAL : ASL_ENOTSUP;
+    if (p->in_halo < 0 || p->in2_halo < 0 || p->out_halo < 0 || p->out_coff < 0 || p->out_coff + p->cout > p->out_ctot) return ASL_EINVAL;
+    if ((p->out_ctot & 7) || (p->out_coff & 7) || (p->relu != 0 && p->relu != 1)) return ASL_EINVAL;
+    const long long wk = (long long)p->cin + p->cin2;
+    if (p->w_rows < p->cout || (p->w_rows & 127) || wk * p->w_rows * 2 > 0x7fffffffLL) return ASL_EINVAL;
+    if (((uintptr_t)t & 15) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)scale & 15) ||
+        ((uintptr_t)bias & 15) || ((uintptr_t)pre_scale & 15))
+        return ASL_EINVAL;
+    const long long M = (long long)p->n * p->h * p->w;
+    if (M > 0x7fffffffLL) return ASL_EINVAL;
+    const int wp = p->w + 2 * p->in_halo, hp = p->h + 2 * p->in_halo;
+    const int w2 = p->w * p->stride2, h2 = p->h * p->stride2;
+    const int wp2 = w2 + 2 * p->in2_halo, hp2 = h2 + 2 * p->in2_halo;
+    const int owp = p->w + 2 * p->out_halo, ohp = p->h + 2 * p->out_halo;
+    GemmArgs a = {};
+    a.x = (const char*)t; a.w = (const char*)w; a.scale = scale; a.bias = bias; a.res = nullptr; a.y = (char*)y;
+    a.M = (int)M; a.N = p->cout;
+    a.dOW = make_fastdiv(p->w); a.dOHW = make_fastdiv(p->h * p->w); a.dODHW = make_fastdiv(p->h * p->w);
+    a.in_sn = (long long)hp * wp * p->cin; a.in_sd = 0; a.in_sh = wp * p->cin; a.in_sw = p->cin;
+    a.in_off0 = (p->in_halo * wp + p->in_halo) * p->cin;
+    a.out_sn = (long long)ohp * owp * p->out_ctot; a.out_sd = 0; a.out_sh = owp * p->out_ctot; a.out_sw = p->out_ctot;
+    a.out_off0 = (p->out_halo * owp + p->out_halo) * p->out_ctot + p->out_coff;
+    a.KH = 1; a.KW = 1; a.ntaps = 1; a.tap_sd = a.tap_sh = a.tap_sw = 0;
+    a.ksteps_per_tap = p->cin / 64;
+    a.wk = (int)wk;
+    a.x_bytes = 2LL * p->n * a.in_sn; a.w_bytes = 2 * wk * p->w_rows;
+    a.relu = p->relu; a.out_f32 = 0; a.res_f32 = 0; a.out_lo = a.res_lo = 0;
+    a.x2 = (const char*)x; a.pre_scale = pre_scale;
+    a.in2_sn = (long long)hp2 * wp2 * p->cin2; a.in2_sh = p->stride2 * wp2 * p->cin2; a.in2_sw = p->stride2 * p->cin2;
+    a.in2_off0 = (p->in2_halo * wp2 + p->in2_halo) * p->cin2;
+    a.x2_bytes = 2LL * p->n * a.in2_sn;
+    a.nsteps2 = p->cin2 / 64;
+    // 32-bit DMA offsets within a tile's window of images, as in asl_gather_gemm_bf16
+    {
+        const long long imgs = 256 / ((long long)p->h * p->w) + 2;
+        if (2 * (imgs * a.in_sn + a.in_off0 + p->cin) > 0x7fffffffLL || 2 * (imgs * a.in2_sn + a.in2_off0 + p->cin2) > 0x7fffffffLL)
+            return ASL_EINVAL;
+    }
+    // the weight columns of the primary operand follow the second operand's: the kernel's column offset runs on
+    return launch<128, 128, 64, 2, 4, false, true>(a, (hipStream_t)stream);
 }

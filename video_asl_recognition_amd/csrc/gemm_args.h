@@ -27,6 +27,14 @@ struct GemmArgs {
     int relu, out_f32, res_f32;
     int tiles_m, tiles_n;
     int out_lo, res_lo;          // split-precision output / residual (SPLIT instances): element offset of the lo half
+    // DUAL instances: a second activation operand whose K steps run FIRST (a 1x1 tap: nsteps2 steps of BK contiguous
+    // channels per output pixel, weights in the first nsteps2 * BK columns of every row); when they are done the
+    // accumulator is multiplied by pre_scale[channel] and the primary operand's steps accumulate on top
+    const char* x2;
+    const float* pre_scale;
+    long long in2_sn, x2_bytes;
+    int in2_sh, in2_sw, in2_off0;
+    int nsteps2;
 };
 
 }  // namespace asl_detail

@@ -20,7 +20,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib as L
-from .packing import (PackedConv, bn_scale_bias, pack_conv, pack_entry_conv, pack_entry_ds, pack_linear, pack_stem,
+from .packing import (pack_dual1x1, PackedConv, bn_scale_bias, pack_conv, pack_entry_conv, pack_entry_ds, pack_linear, pack_stem,
                       pack_stem_planar)
 from .spec import RESNET_LAYERS, SPECS, ModelSpec, param_shapes, resnet_blocks
 
@@ -122,6 +122,10 @@ class AslClipModel:
         # measured no faster -- ResNet-50 + BiLSTM 16 x 64 17.65 against 16.39 ms (the recurrence's 128 short launches
         # per chunk sit in front of the stream's next chunk), two-stream transformer 8 x 128 4.23 ms either way
         self.chunk_heads = (os.environ.get("ASL_CHUNK_HEADS", "0") == "1") if chunk_heads is None else bool(chunk_heads)
+        # ResNet-50: the last 1x1 conv of a bottleneck and its projected shortcut (1x1, stride 1 or 2) as ONE launch, the
+        # shortcut's K steps first and its sum rescaled in the accumulator (asl_conv1x1_dual_bf16): the shortcut tensor is
+        # neither written nor read back.  ASL_FUSE_SHORTCUT=0 keeps the two launches.
+        self.fuse_shortcut = os.environ.get("ASL_FUSE_SHORTCUT", "1") == "1"
         self._keep_heads = None
         self._w: Dict[str, PackedConv] = {}
         self._fc_w = self._fc_b = None
@@ -165,6 +169,13 @@ class AslClipModel:
                         c1 = w[f"{prefix}.conv1"]
                         w[f"{prefix}.entry"] = pack_entry_conv(sd[f"{prefix}.conv1.weight"], dev, c1.scale, c1.bias)
                         w[f"{prefix}.entry_ds"] = pack_entry_ds(sd[f"{prefix}.downsample.0.weight"], dev, s, b)
+                    if not split and nconv == 3 and self.fuse_shortcut:
+                        # bottleneck exit + projected shortcut as one launch (asl_conv1x1_dual_bf16)
+                        c3 = w[f"{prefix}.conv3"]
+                        dual = pack_dual1x1(sd[f"{prefix}.conv3.weight"], c3.scale, c3.bias,
+                                            sd[f"{prefix}.downsample.0.weight"], s, b, dev)
+                        if dual is not None:
+                            w[f"{prefix}.dual"], w[f"{prefix}.dual_pre"] = dual
         elif spec.backbone == "i3d":
             from .i3d import pack_i3d_weights
             w = pack_i3d_weights(spec, sd, dev)
@@ -257,6 +268,7 @@ class AslClipModel:
             for bi, (prefix, cin, planes, stride, ds) in enumerate(blocks):
                 oh, ow = x.h // stride, x.w // stride
                 w = self._w
+                idt = x                                           # the block's shortcut: its input, or a projection of it
                 # the next block is a stride-2 entry that can take its input as cells, and this block's last kernel can
                 # write them (the paired fused block; the 8-wave 3x3 kernel: 128 channels and up, whole 128-channel tiles)
                 nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
@@ -296,14 +308,21 @@ class AslClipModel:
                     t2 = pool.get(oh, ow, planes * cm)
                     conv_op(w[prefix + ".conv2"], t1, t2, stride, 1, True)
                     idt = x
-                    if ds:
-                        idt = pool.get(oh, ow, planes * 4 * cm)
-                        conv_op(w[prefix + ".ds"], x, idt, stride, 0, False)
                     y = pool.get(oh, ow, planes * 4 * cm)
-                    conv_op(w[prefix + ".conv3"], t2, y, 1, 0, True, res=idt)
+                    if ds and (prefix + ".dual") in w and self.conv_variant in (0, L.CONV_GATHER):
+                        # conv3 and the projected shortcut in one launch: the shortcut tensor is never materialised
+                        pc, pre = w[prefix + ".dual"], w[prefix + ".dual_pre"]
+                        dp = L.Dual1x1Params(n=0, h=oh, w=ow, cin=t2.c, in_halo=t2.halo, cin2=x.c, in2_halo=x.halo, stride2=stride,
+                                             cout=pc.cout, out_halo=y.halo, out_ctot=y.c, out_coff=0, relu=1, w_rows=pc.w_rows)
+                        add(L.OP_CONV1X1_DUAL, dp, (t2.t, x.t, pc.w, pc.scale, pc.bias, pre, y.t), conv=True, keep=(t2, x, y, pc, pre))
+                    else:
+                        if ds:
+                            idt = pool.get(oh, ow, planes * 4 * cm)
+                            conv_op(w[prefix + ".ds"], x, idt, stride, 0, False)
+                        conv_op(w[prefix + ".conv3"], t2, y, 1, 0, True, res=idt)
                     pool.put(t1)
                     pool.put(t2)
-                if ds:
+                if idt is not x:
                     pool.put(idt)
                 pool.put(x)
                 x = y

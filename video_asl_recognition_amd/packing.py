@@ -56,6 +56,30 @@ def pack_conv(w: torch.Tensor, device, cin_phys: Optional[int] = None, scale=Non
     return PackedConv(p, scale, bias, cout, reps * cin_phys, (kd, kh, kw), w_rows)
 
 
+def pack_dual1x1(w_main: torch.Tensor, s_main, b_main, w_short: torch.Tensor, s_short, b_short, device):
+    """Weights of asl_conv1x1_dual_bf16 for y = act(bn_main(conv_main(t)) + bn_short(conv_short(x))), both 1x1:
+    bf16 [w_rows][cin_short + cin_main] (the shortcut's columns first), scale = the main BatchNorm's scale,
+    pre_scale = shortcut scale / main scale, bias = the two biases added.  Returns (PackedConv, pre_scale), or None when a
+    main-branch scale is too small to divide by (the caller keeps the two-launch form)."""
+    w_main = w_main.to(torch.float32).reshape(w_main.shape[0], -1)
+    w_short = w_short.to(torch.float32).reshape(w_short.shape[0], -1)
+    cout, cin = w_main.shape
+    cin2 = w_short.shape[1]
+    s_main, s_short = s_main.to(torch.float32).cpu(), s_short.to(torch.float32).cpu()
+    if cin % 64 or cin2 % 64 or bool((s_main.abs() < 1e-6 * s_short.abs().clamp_min(1e-30)).any()):
+        return None
+    w_rows = _round_up(cout, 128)
+    p = torch.zeros(w_rows, cin2 + cin, dtype=torch.float32)
+    p[:cout, :cin2] = w_short
+    p[:cout, cin2:] = w_main
+    pre = torch.ones(w_rows, dtype=torch.float32)
+    pre[:cout] = s_short / s_main
+    bias = (b_main.to(torch.float32).cpu() + b_short.to(torch.float32).cpu()).contiguous()
+    pc = PackedConv(p.to(torch.bfloat16).contiguous().to(device), s_main.contiguous().to(device), bias.to(device), cout,
+                    cin2 + cin, (1, 1, 1), w_rows)
+    return pc, pre.contiguous().to(device)
+
+
 def pack_stem(w: torch.Tensor, device, scale=None, bias=None) -> PackedConv:
     """First-layer weights [cout, 3, kh, kw] (kw <= 8) -> bf16 [w_rows][kh * 32]: per filter row
     8 pixels x 4 channels, zero where q >= kw or c == 3."""
