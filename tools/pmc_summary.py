@@ -35,7 +35,7 @@ def main(argv):
     for p in paths:
         with open(p) as f:
             for row in csv.DictReader(f):
-                k = row["Kernel_Name"].split("(")[0][-60:]
+                k = row["Kernel_Name"].split("(")[0][-96:]
                 c = row["Counter_Name"]
                 agg[k][c] += float(row["Counter_Value"])
                 calls[k][c] += 1
