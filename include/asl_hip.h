@@ -322,6 +322,13 @@ int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, int s, int h
                       const float mean[3], const float std_[3], void* y, float* clips_f32,
                       asl_stream_t stream);
 
+/* The same arithmetic, written as the bf16 clip tensor [n][3][s][s] (the planar input asl_stem_pool_bf16 reads in place
+ * when asl_stem_pool_params.planar is set): 6 bytes per pixel leave the kernel instead of 8 plus halo, and the stem
+ * reads them once.  Values are bit-identical to the packed form's. */
+int asl_preprocess_u8_planar(const uint8_t* frames, int n, int h0, int w0, int s,
+                             const float mean[3], const float std_[3], void* clips_bf16,
+                             asl_stream_t stream);
+
 /* nn.MaxPool2d(3, 2, 1) on halo'd NHWC bf16 (c % 8 == 0).  Input values must be >= 0
  * wherever a window overlaps the halo (true after ReLU): the zero halo then acts as -inf. */
 int asl_maxpool3x3s2_nhwc(const void* x, int n, int h, int w, int c, int in_halo,
@@ -453,7 +460,8 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
  *   ASL_OP_MAXPOOL       NULL                    x, y                                    n, h, w, c, in_halo, out_halo
  *   ASL_OP_AVGPOOL       NULL                    x, y_f32, y_bf16                        n, h, w, c, halo, ld_bf16, lo_off
  *   ASL_OP_PACK_CLIPS    NULL                    clips, y                                in_f32, n, s, halo
- *   ASL_OP_PREPROCESS    NULL                    frames, y, clips_f32                    n, h0, w0, s, halo / mean[3], std[3]
+ *   ASL_OP_PREPROCESS    NULL                    frames, y, clips_f32                    n, h0, w0, s, halo, planar / mean[3], std[3]
+ *                        (planar != 0: y is the bf16 clip tensor of asl_preprocess_u8_planar; halo and clips_f32 unused)
  *   ASL_OP_MEAN_T        NULL                    x, y                                    rows, t, c
  *   ASL_OP_HEAD          NULL                    x, w, b, y                              m, f, c
  *   ASL_OP_BASIC_BLOCK   asl_block_params*       x, w1, scale1, bias1, w2, scale2, bias2, y

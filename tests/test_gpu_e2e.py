@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -188,6 +189,28 @@ def test_chunking_and_streams_do_not_change_results(gpu):
         else:
             assert torch.equal(f, ref), f"chunk={chunk} streams={streams} changed the features"
         del m
+
+
+def test_classify_clip_resizes_into_the_clip_tensor_the_stem_reads(gpu, monkeypatch):
+    """uint8 frames are resized and normalised straight into bf16 clips [n][3][S][S], which the stem reads in place:
+    the logits are those of forward(preprocess(frames)) bit for bit (ragged chunks, two streams, two calls), and the
+    packed-input road (ASL_PLANAR_STEM=0) agrees within the stem kernels' accumulation order."""
+    from video_asl_recognition_amd import AslClipModel
+    frames = O.make_frames(2, 4, 60, 80, 3).cuda()
+    m = AslClipModel("resnet18_mean", seed=3, frames_per_chunk=3, streams=2)
+    assert m._planar_input()
+    logits = m(m.preprocess(frames)).clone()
+    rp, ri = F.softmax(logits, -1).topk(5, -1)
+    for _ in range(2):
+        idx, prob = m.classify_clip(frames, topk=5)
+        assert torch.equal(idx, ri)
+        torch.testing.assert_close(prob, rp, rtol=1e-5, atol=1e-8)
+    monkeypatch.setenv("ASL_PLANAR_STEM", "0")
+    m2 = AslClipModel("resnet18_mean", seed=3, frames_per_chunk=3, streams=2)
+    assert not m2._planar_input()
+    idx2, prob2 = m2.classify_clip(frames, topk=5)
+    assert torch.equal(idx2[:, 0], ri[:, 0])
+    torch.testing.assert_close(prob2.sort(1).values, rp.sort(1).values, rtol=2e-3, atol=1e-6)
 
 
 @pytest.mark.parametrize("name,B,T", [("resnet50_bilstm", 5, 16), ("twostream_transformer", 3, 32)])

@@ -791,8 +791,9 @@ def test_linear(gpu, m, n, k):
     torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("h0,w0,s", [(240, 320, 224), (60, 80, 112), (224, 224, 224), (100, 90, 224)])
-def test_preprocess_matches_interpolate(gpu, h0, w0, s):
+@pytest.mark.parametrize("h0,w0,s", [(240, 320, 224), (60, 80, 112), (224, 224, 224), (100, 90, 224), (480, 640, 112),
+                                     (37, 53, 112)])
+def test_preprocess_matches_interpolate(gpu, h0, w0, s, monkeypatch):
     from video_asl_recognition_amd import _lib as L
     frames = O.make_frames(1, 3, h0, w0, seed=5)
     ref = O.preprocess(frames, s)[0]                       # [3,3,s,s] fp32
@@ -807,6 +808,40 @@ def test_preprocess_matches_interpolate(gpu, h0, w0, s):
     packed = x0.float().cpu()
     assert packed[:, :3].abs().sum() == 0 and packed[..., 3].abs().sum() == 0
     _assert_bf16_close(packed[:, 3:-3, 3:-3, :3].permute(0, 3, 1, 2), ref)
+    # the planar form (the bf16 clip tensor the stem reads in place): the packed form's values, bit for bit
+    planar = torch.full((3, 3, s, s), 9.0, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib.asl_preprocess_u8_planar(_p(fd), 3, h0, w0, s, mean, std, _p(planar), None))
+    torch.cuda.synchronize()
+    assert torch.equal(planar.cpu(), x0[:, 3:-3, 3:-3, :3].permute(0, 3, 1, 2).cpu())
+    # the kernel that reads the frames directly (what runs when a group's source rows do not fit LDS, as at 480 x 640
+    # here, or the frames are not 16-byte aligned) and the one that stages them through LDS: identical outputs
+    monkeypatch.setenv("ASL_PREPROCESS_DIRECT", "1")
+    x1 = torch.full((3, s + 6, s + 6, 4), 9.0, dtype=torch.bfloat16, device="cuda")
+    out1 = torch.empty(3, 3, s, s, device="cuda")
+    L.check(L.lib.asl_preprocess_u8(_p(fd), 3, h0, w0, s, 3, mean, std, _p(x1), _p(out1), None))
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x0) and torch.equal(out1, out)
+    monkeypatch.delenv("ASL_PREPROCESS_DIRECT")
+    shifted = torch.empty(fd.numel() + 3, dtype=torch.uint8, device="cuda")
+    shifted[3:] = fd.reshape(-1)                                       # frames at an address that is 3 mod 16
+    x2 = torch.full((3, s + 6, s + 6, 4), 9.0, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib.asl_preprocess_u8(C.c_void_p(shifted.data_ptr() + 3), 3, h0, w0, s, 3, mean, std, _p(x2), None, None))
+    torch.cuda.synchronize()
+    assert torch.equal(x2, x0)
+
+
+def test_preprocess_planar_rejects(gpu):
+    from video_asl_recognition_amd import _lib as L
+    mean = (C.c_float * 3)(*O.IMAGENET_MEAN)
+    std = (C.c_float * 3)(*O.IMAGENET_STD)
+    bad = (C.c_float * 3)(0.2, 0.0, 0.2)
+    fd = torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device="cuda")
+    y = torch.empty(1, 3, 4, 4, dtype=torch.bfloat16, device="cuda")
+    lib = L.lib
+    assert lib.asl_preprocess_u8_planar(None, 1, 8, 8, 4, mean, std, _p(y), None) == L.ASL_EINVAL
+    assert lib.asl_preprocess_u8_planar(_p(fd), 0, 8, 8, 4, mean, std, _p(y), None) == L.ASL_EINVAL
+    assert lib.asl_preprocess_u8_planar(_p(fd), 1, 8, 8, 4, mean, bad, _p(y), None) == L.ASL_EINVAL
+    assert lib.asl_preprocess_u8_planar(_p(fd), 1, 8, 8, 4, mean, std, C.c_void_p(y.data_ptr() + 1), None) == L.ASL_EINVAL
 
 
 def test_softmax_topk(gpu):

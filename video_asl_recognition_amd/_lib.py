@@ -129,6 +129,7 @@ _PROTOS = {
     "asl_pack_clips": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
     "asl_pack_clips_3d": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "asl_preprocess_u8": ([_P, _I, _I, _I, _I, _I, _F3, _F3, _P, _P, _P], C.c_int),
+    "asl_preprocess_u8_planar": ([_P, _I, _I, _I, _I, _F3, _F3, _P, _P], C.c_int),
     "asl_maxpool3x3s2_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _I, _P], C.c_int),
     "asl_maxpool3x3s2_split_nhwc": ([_P, _I, _I, _I, _I, _I, _P, _I, _P], C.c_int),
     "asl_maxpool3d_ndhwc": ([C.POINTER(Pool3dParams), _P, _P, _P], C.c_int),

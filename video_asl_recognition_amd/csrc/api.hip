@@ -199,8 +199,9 @@ extern "C" int asl_run_ops(const asl_op* ops, int count, const asl_stream_t* str
                     rc = asl_pack_clips(p[0], i[0], i[1], i[2], i[3], p[1], s);
                     break;
                 case ASL_OP_PREPROCESS:
-                    rc = asl_preprocess_u8((const uint8_t*)p[0], i[0], i[1], i[2], i[3], i[4], o.f, o.f + 3, p[1],
-                                           (float*)p[2], s);
+                    rc = i[5] ? asl_preprocess_u8_planar((const uint8_t*)p[0], i[0], i[1], i[2], i[3], o.f, o.f + 3, p[1], s)
+                              : asl_preprocess_u8((const uint8_t*)p[0], i[0], i[1], i[2], i[3], i[4], o.f, o.f + 3, p[1],
+                                                  (float*)p[2], s);
                     break;
                 case ASL_OP_MEAN_T:
                     rc = asl_mean_t_f32((const float*)p[0], i[0], i[1], i[2], (float*)p[1], s);

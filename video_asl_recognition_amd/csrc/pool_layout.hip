@@ -104,10 +104,21 @@ __global__ __launch_bounds__(256) void pack_clips_bf16x8_kernel(const short* __r
 // Source index and weights follow ATen's area_pixel_compute_source_index /
 // guard_index_and_lambda for align_corners=False (scale = in/out in fp32).
 // ---------------------------------------------------------------------------------------
+// PLANAR: y is the bf16 clip tensor [n][3][s][s] itself (what the planar-input stem reads in place; kHalo0 = 0): 6 bytes
+// written per pixel instead of 8 plus halo, and no packed copy for the stem to re-read.
+#ifndef ASL_PRE_ROWS
+#define ASL_PRE_ROWS 4
+#endif
+constexpr int kPreRows = ASL_PRE_ROWS;     // output rows per workgroup pass
+
+template <bool PLANAR>
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ frames, int n, int h0, int w0,
                                                          int s, int kHalo0, float m0, float m1, float m2, float i0,
                                                          float i1, float i2, short* __restrict__ y,
                                                          float* __restrict__ clips_f32) {
+    // fused multiply-adds are written out (and the compiler's own fusing is off): which products it fuses differs
+    // between the two instantiations, and the two output forms are specified to hold the same values bit for bit
+#pragma clang fp contract(off)
     const int sp = s + 2 * kHalo0;
     const float sy = (float)h0 / (float)s, sx = (float)w0 / (float)s;
     // 1/255 and 1/std as multiplications: a true fp32 division is ~10 instructions and the kernel does six per
@@ -118,14 +129,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
     // A workgroup takes kRows consecutive output rows (row index and vertical weights are wave-uniform), lanes
     // run along the row; a lane first issues the source loads of all its rows, then blends and stores: one load
     // round trip per kRows pixels instead of one per pixel (the kernel is bound by that latency, not by bytes).
-    constexpr int kRows = 4;
+    constexpr int kRows = kPreRows;
     const unsigned rows = (unsigned)n * (unsigned)sp;       // < 2^31: checked on the host
     const unsigned groups = (rows + kRows - 1) / kRows;
     for (unsigned grp = blockIdx.x; grp < groups; grp += gridDim.x)
     for (int px = threadIdx.x; px < sp; px += 256) {
         const int ox = px - kHalo0;
         const bool col_in = ox >= 0 && ox < s;
-        float fx = sx * ((float)ox + 0.5f) - 0.5f;
+        float fx = __builtin_fmaf(sx, (float)ox + 0.5f, -0.5f);      // (fused, as the CPU library computes it)
         fx = fx < 0.f ? 0.f : fx;
         int x0 = (int)fx;
         x0 = x0 < w0 - 1 ? x0 : w0 - 1;
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
             q0[r] = q1[r] = 0;
             ly[r] = 0.f;
             if (live[r]) {
-                float fy = sy * ((float)oy + 0.5f) - 0.5f;
+                float fy = __builtin_fmaf(sy, (float)oy + 0.5f, -0.5f);
                 fy = fy < 0.f ? 0.f : fy;
                 int y0 = (int)fy;
                 y0 = y0 < h0 - 1 ? y0 : h0 - 1;
@@ -181,15 +192,183 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
                 for (int c = 0; c < 3; ++c) {
                     const float v00 = (float)(unsigned)((q0[r] >> (8 * c)) & 0xff), v01 = (float)(unsigned)((q0[r] >> (8 * c + 24)) & 0xff);
                     const float v10 = (float)(unsigned)((q1[r] >> (8 * c)) & 0xff), v11 = (float)(unsigned)((q1[r] >> (8 * c + 24)) & 0xff);
-                    const float v = hy * (hx * v00 + lx * v01) + ly[r] * (hx * v10 + lx * v11);
-                    const float z = (v * inv255 - mean[c]) * isd[c];
+                    const float top = __builtin_fmaf(lx, v01, hx * v00), bot = __builtin_fmaf(lx, v11, hx * v10);
+                    const float v = __builtin_fmaf(ly[r], bot, hy * top);
+                    const float z = __builtin_fmaf(v, inv255, -mean[c]) * isd[c];
                     o[c] = f32_to_bf16(z);
-                    if (clips_f32) clips_f32[(((long long)img * 3 + c) * s + oy) * (long long)s + ox] = z;
+                    if (PLANAR) y[(((long long)img * 3 + c) * s + oy) * (long long)s + ox] = o[c];
+                    else if (clips_f32) clips_f32[(((long long)img * 3 + c) * s + oy) * (long long)s + ox] = z;
                 }
             }
-            *(bf16x4*)(y + 4 * ((long long)row * sp + px)) = o;
+            if (!PLANAR) *(bf16x4*)(y + 4 * ((long long)row * sp + px)) = o;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same resize through LDS, for frames whose source rows of a group of output rows fit there (any upscale, and
+// downscales up to about 1.3x at 320-pixel rows): the rows a group of kStageRows output rows blends from are one
+// contiguous byte range of the frame, copied into LDS with aligned 16-byte loads; the six bytes of a source pixel pair
+// then come from three aligned LDS words and two byte-alignment instructions.  The direct kernel's unaligned 8-byte
+// global loads run at a fraction of the aligned rate and bound it; the arithmetic here is the same, operation for
+// operation, so the two kernels' outputs are identical.
+// ---------------------------------------------------------------------------------------
+#ifndef ASL_STAGE_ROWS
+#define ASL_STAGE_ROWS 8
+#endif
+constexpr int kStageRows = ASL_STAGE_ROWS;
+constexpr int kStageMaxBytes = 32768;
+
+// ATen's area_pixel_compute_source_index + guard_index_and_lambda (align_corners=False)
+__host__ __device__ inline void resize_src_index(float scale, int o, int lim, int& i0, int& i1, float& l) {
+    float f = __builtin_fmaf(scale, (float)o + 0.5f, -0.5f);
+    f = f < 0.f ? 0.f : f;
+    i0 = (int)f;
+    i0 = i0 < lim - 1 ? i0 : lim - 1;
+    i1 = i0 + (i0 < lim - 1 ? 1 : 0);
+    l = f - (float)i0;
+    l = l < 0.f ? 0.f : (l > 1.f ? 1.f : l);
+}
+
+// bytes [first source row of the group, end of its last) of image `img`, for padded output rows [r0, r0 + kStageRows)
+__host__ __device__ inline bool stage_range(int r0, int halo, int s, int h0, int w0, float sy, int& ylo, int& yhi) {
+    const int oy_lo = r0 - halo > 0 ? r0 - halo : 0;
+    const int oy_hi = r0 + kStageRows - 1 - halo < s - 1 ? r0 + kStageRows - 1 - halo : s - 1;
+    if (oy_lo > oy_hi) return false;
+    int t;
+    float l;
+    resize_src_index(sy, oy_lo, h0, ylo, t, l);
+    resize_src_index(sy, oy_hi, h0, t, yhi, l);
+    return true;
+}
+
+template <bool PLANAR>
+__global__ __launch_bounds__(256) void preprocess_staged_kernel(const uint8_t* __restrict__ frames, int n, int h0, int w0,
+                                                                int s, int halo, float m0, float m1, float m2, float i0,
+                                                                float i1, float i2, short* __restrict__ y,
+                                                                float* __restrict__ clips_f32, int groups_per_img) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_lds[];
+    const int sp = s + 2 * halo;
+    const float sy = (float)h0 / (float)s, sx = (float)w0 / (float)s;
+    const float mean[3] = {m0, m1, m2}, isd[3] = {1.f / i0, 1.f / i1, 1.f / i2};
+    const float inv255 = 1.f / 255.f;
+    const int img = blockIdx.x / groups_per_img, r0 = (blockIdx.x - img * groups_per_img) * kStageRows;
+    const int r_end = r0 + kStageRows < sp ? r0 + kStageRows : sp;
+    const int tid = threadIdx.x;
+    const long long total = (long long)n * h0 * w0 * 3;
+    const int row_bytes = w0 * 3;
+    int ylo = 0, yhi = 0;
+    unsigned shift = 0;
+    if (stage_range(r0, halo, s, h0, w0, sy, ylo, yhi)) {
+        const long long start = ((long long)img * h0 + ylo) * row_bytes, end = ((long long)img * h0 + yhi + 1) * row_bytes;
+        const long long astart = start & ~15LL;             // (frames is 16-byte aligned: checked on the host)
+        shift = (unsigned)(start - astart);
+        const int n16 = (int)((end - astart + 15) >> 4);
+        for (int base = 0; base < n16; base += 1024) {
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + k * 256 + tid;
+                const long long o = astart + 16LL * i;
+                v[k] = uint4{0, 0, 0, 0};
+                if (i < n16) {
+                    if (o + 16 <= total) v[k] = *(const uint4*)(frames + o);
+                    else {                                   // the tensor's last, partial 16 bytes
+                        unsigned w[4] = {0, 0, 0, 0};
+                        for (int b = 0; b < 16 && o + b < total; ++b) w[b >> 2] |= (unsigned)frames[o + b] << (8 * (b & 3));
+                        v[k] = uint4{w[0], w[1], w[2], w[3]};
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + k * 256 + tid;
+                if (i < n16) ((uint4*)stage_lds)[i] = v[k];
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned* lds32 = (const unsigned*)stage_lds;
+    for (int px = tid; px < sp; px += 256) {
+        const int ox = px - halo;
+        const bool col_in = ox >= 0 && ox < s;
+        int x0, x1;
+        float lx;
+        resize_src_index(sx, ox, w0, x0, x1, lx);
+        const float hx = 1.f - lx;
+        const unsigned bx = shift + 3u * (unsigned)x0;
+        const bool pair = x1 != x0;
+        for (int r = r0; r < r_end; ++r) {
+            const int oy = r - halo;
+            const unsigned row = (unsigned)img * (unsigned)sp + (unsigned)r;
+            bf16x4 o = {0, 0, 0, 0};
+            if (col_in && oy >= 0 && oy < s) {
+                int y0, y1;
+                float ly;
+                resize_src_index(sy, oy, h0, y0, y1, ly);
+                const float hy = 1.f - ly;
+                unsigned d[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned b = (unsigned)((t ? y1 : y0) - ylo) * (unsigned)row_bytes + bx;
+                    const unsigned wi = b >> 2, sh = b & 3;
+                    const unsigned w_0 = lds32[wi], w_1 = lds32[wi + 1], w_2 = lds32[wi + 2];
+                    d[t][0] = __builtin_amdgcn_alignbyte(w_1, w_0, sh);
+                    d[t][1] = __builtin_amdgcn_alignbyte(w_2, w_1, sh);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const unsigned long long q0 = ((unsigned long long)d[0][1] << 32) | d[0][0];
+                    const unsigned long long q1 = ((unsigned long long)d[1][1] << 32) | d[1][0];
+                    const int s1 = pair ? 8 * c + 24 : 8 * c;
+                    const float v00 = (float)(unsigned)((q0 >> (8 * c)) & 0xff), v01 = (float)(unsigned)((q0 >> s1) & 0xff);
+                    const float v10 = (float)(unsigned)((q1 >> (8 * c)) & 0xff), v11 = (float)(unsigned)((q1 >> s1) & 0xff);
+                    const float top = __builtin_fmaf(lx, v01, hx * v00), bot = __builtin_fmaf(lx, v11, hx * v10);
+                    const float v = __builtin_fmaf(ly, bot, hy * top);
+                    const float z = __builtin_fmaf(v, inv255, -mean[c]) * isd[c];
+                    o[c] = f32_to_bf16(z);
+                    if (PLANAR) y[(((long long)img * 3 + c) * s + oy) * (long long)s + ox] = o[c];
+                    else if (clips_f32) clips_f32[(((long long)img * 3 + c) * s + oy) * (long long)s + ox] = z;
+                }
+            }
+            if (!PLANAR) *(bf16x4*)(y + 4 * ((long long)row * sp + px)) = o;
+        }
+    }
+}
+
+// LDS bytes the staged kernel needs for this geometry, or 0 when a group's source rows do not fit (or the frames are
+// not 16-byte aligned): the direct kernel then runs
+static int preprocess_stage_bytes(const void* frames, int h0, int w0, int s, int halo) {
+    if (((uintptr_t)frames & 15) || getenv("ASL_PREPROCESS_DIRECT")) return 0;
+    const float sy = (float)h0 / (float)s;
+    const int sp = s + 2 * halo;
+    int rows = 0;
+    for (int r0 = 0; r0 < sp; r0 += kStageRows) {
+        int ylo, yhi;
+        if (stage_range(r0, halo, s, h0, w0, sy, ylo, yhi) && yhi - ylo + 1 > rows) rows = yhi - ylo + 1;
+    }
+    // + 15 bytes of alignment shift, rounded up to whole 16-byte pieces, + the two words a pixel read may run past
+    const long long need = (((long long)rows * w0 * 3 + 15 + 15) & ~15LL) + 16;
+    return need <= kStageMaxBytes ? (int)need : 0;
+}
+
+template <bool PLANAR>
+static int preprocess_launch(const uint8_t* frames, int n, int h0, int w0, int s, int halo, const float* mean, const float* std_,
+                             void* y, float* clips_f32, hipStream_t st) {
+    const int sp = s + 2 * halo;
+    const int lds = preprocess_stage_bytes(frames, h0, w0, s, halo);
+    const long long groups = (long long)n * ((sp + kStageRows - 1) / kStageRows);
+    if (lds > 0 && groups <= 0x7fffffffLL) {
+        hipLaunchKernelGGL(preprocess_staged_kernel<PLANAR>, dim3((unsigned)groups), dim3(256), lds, st, frames, n, h0, w0, s, halo,
+                           mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], (short*)y, clips_f32,
+                           (sp + kStageRows - 1) / kStageRows);
+        return (int)hipGetLastError();
+    }
+    const long long rows = ((long long)n * sp + kPreRows - 1) / kPreRows;
+    hipLaunchKernelGGL(preprocess_kernel<PLANAR>, dim3((unsigned)(rows < (1 << 20) ? rows : (1 << 20))), dim3(256), 0, st, frames, n, h0, w0,
+                       s, halo, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], (short*)y, clips_f32);
+    return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -566,11 +745,17 @@ extern "C" int asl_preprocess_u8(const uint8_t* frames, int n, int h0, int w0, i
     for (int c = 0; c < 3; ++c)
         if (!(std_[c] > 0.f)) return ASL_EINVAL;
     if ((long long)n * (s + 2 * halo) >= 0x7fffffffLL) return ASL_EINVAL;
-    const long long rows = ((long long)n * (s + 2 * halo) + 3) / 4;     // four output rows per workgroup
-    hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)(rows < (1 << 20) ? rows : (1 << 20))), dim3(256), 0, (hipStream_t)stream, frames, n, h0, w0,
-                       s, halo, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], (short*)y,
-                       clips_f32);
-    return (int)hipGetLastError();
+    return preprocess_launch<false>(frames, n, h0, w0, s, halo, mean, std_, y, clips_f32, (hipStream_t)stream);
+}
+
+extern "C" int asl_preprocess_u8_planar(const uint8_t* frames, int n, int h0, int w0, int s, const float mean[3],
+                                        const float std_[3], void* clips_bf16, asl_stream_t stream) {
+    if (!frames || !clips_bf16 || !mean || !std_ || n <= 0 || h0 <= 0 || w0 <= 0 || s <= 0 || ((uintptr_t)clips_bf16 & 1))
+        return ASL_EINVAL;
+    for (int c = 0; c < 3; ++c)
+        if (!(std_[c] > 0.f)) return ASL_EINVAL;
+    if ((long long)n * s >= 0x7fffffffLL) return ASL_EINVAL;
+    return preprocess_launch<true>(frames, n, h0, w0, s, 0, mean, std_, clips_bf16, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int asl_maxpool3d_ndhwc(const asl_pool3d_params* p, const void* x, void* y, asl_stream_t stream) {

@@ -115,7 +115,7 @@ class AslClipModel:
         if self.parity_mode and self.spec.backbone not in RESNET_LAYERS:
             raise NotImplementedError("parity mode covers the ResNet backbones")
         # ResNet stem straight from the bf16 clip tensor (no packed, halo'd copy of the input): ASL_PLANAR_STEM=0 goes
-        # back to pack + packed-input stem (uint8 frames always take that road: preprocess writes the packed form)
+        # back to pack + packed-input stem (and uint8 frames are then resized into the packed form instead of into clips)
         self.planar_stem = os.environ.get("ASL_PLANAR_STEM", "1") != "0"
         # BiLSTM / transformer heads per chunk of whole clips, on the chunk's stream, under the other stream's backbone
         # launches instead of one head over the whole batch after the backbone.  Opt-in (argument, or ASL_CHUNK_HEADS=1):
@@ -409,14 +409,13 @@ class AslClipModel:
                 sp = plan["stem_planar"]
                 if sp is not None:
                     # the stem launch of this chunk: on the packed input the fill op writes, or (fill_x0 returned the
-                    # address of the chunk's bf16 clips) on those directly, with no fill
+                    # address of the chunk's bf16 clips: the caller's tensor, or what its fill op writes) on those directly
                     k = g + sp["index"] * g + j
                     rec = sp if direct else plan["ops"][sp["index"]]
                     C.memmove(C.addressof(arr[k]), C.addressof(rec["op"]), C.sizeof(L.Op))
                     arr[k].stream = j
                     if direct:
                         arr[k].ptr[0] = direct
-                        arr[j].kind = L.OP_NOP
                         sp["params"].n = n
                 elif direct:
                     raise RuntimeError("this plan has no launch that reads clips in place")
@@ -486,8 +485,7 @@ class AslClipModel:
         """clips [B,T,3,S,S] -> per-frame features fp32 [B*T, F] (and their bf16 copy)."""
         clips = self._check_clips(clips)
         B, T, _, S, _ = clips.shape
-        # (the conditions under which _build_plan lays down the in-place stem launch)
-        planar = (self.planar_stem and self.spec.backbone in RESNET_LAYERS and self.fused_stem and not self.parity_mode)
+        planar = self._planar_input()
         if planar and clips.dtype != torch.bfloat16:
             clips = clips.to(torch.bfloat16)            # the rounding the packed copy would apply (nearest even)
         esz = clips.element_size()
@@ -496,11 +494,18 @@ class AslClipModel:
 
         def fill(op, c0, n, x0_ptr, in_halo):
             if planar:                                    # the stem kernel reads the clips where they lie
+                op.kind = L.OP_NOP
                 return base + c0 * 3 * S * S * 2
             op.kind = L.OP_PACK_CLIPS
             op.ptr[0], op.ptr[1] = base + c0 * 3 * S * S * esz, x0_ptr
             op.i[0], op.i[1], op.i[2], op.i[3] = in_f32, n, S, in_halo
         return self._run_backbone(B * T, fill, want_bf16, chunk_head, T)
+
+    def _planar_input(self) -> bool:
+        """The stem reads bf16 clips [n][3][S][S] in place (the conditions under which _build_plan lays down that launch).
+        Constant for a model instance: its plans' input buffers then only ever hold the planar form (uint8 frames are
+        resized straight into it), otherwise only the packed one."""
+        return self.planar_stem and self.spec.backbone in RESNET_LAYERS and self.fused_stem and not self.parity_mode
 
     def _check_clips(self, clips):
         if clips.dim() != 5 or clips.shape[2] != 3 or clips.shape[3] != clips.shape[4]:
@@ -645,13 +650,17 @@ class AslClipModel:
         mean = (C.c_float * 3)(*IMAGENET_MEAN)
         std = (C.c_float * 3)(*IMAGENET_STD)
         base = frames.data_ptr()
+        planar = self._planar_input()
 
         def fill(op, c0, n, x0_ptr, in_halo):
             op.kind = L.OP_PREPROCESS
             op.ptr[0], op.ptr[1], op.ptr[2] = base + c0 * H0 * W0 * 3, x0_ptr, None
-            op.i[0], op.i[1], op.i[2], op.i[3], op.i[4] = n, H0, W0, S, in_halo
+            op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5] = n, H0, W0, S, in_halo, int(planar)
             for q in range(3):
                 op.f[q], op.f[3 + q] = IMAGENET_MEAN[q], IMAGENET_STD[q]
+            # planar: the chunk's bf16 clips [n][3][S][S] are written at the head of the plan's input buffer (larger
+            # than they are) and the stem reads them from there
+            return x0_ptr if planar else None
         if self.spec.backbone == "i3d":
             def fill3(f0, n, dst, stream):
                 L.check(L.lib.asl_preprocess_u8(C.c_void_p(base + f0 * H0 * W0 * 3), n, H0, W0, S, 3, mean, std, dst,
