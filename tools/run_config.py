@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs `reps` forwards of one model configuration (for profiling under rocprofv3):
-python tools/run_config.py <spec> <B> <T> [reps]      (STREAMS=<n> overrides the model's stream count)"""
+python tools/run_config.py <spec> <B> <T> [reps]      (STREAMS=<n> / CHUNK=<frames> override the model's stream count / chunk)"""
 import os
 import sys
 import time
@@ -12,7 +12,12 @@ from video_asl_recognition_amd import AslClipModel  # noqa: E402
 
 name, B, T = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
-m = AslClipModel(name, seed=0, **({"streams": int(os.environ["STREAMS"])} if "STREAMS" in os.environ else {}))
+kw = {}
+if "STREAMS" in os.environ:
+    kw["streams"] = int(os.environ["STREAMS"])
+if "CHUNK" in os.environ:
+    kw["frames_per_chunk"] = int(os.environ["CHUNK"])
+m = AslClipModel(name, seed=0, **kw)
 S = m.spec.size
 clips = torch.randn(B, T, 3, S, S, device="cuda").to(torch.bfloat16)
 kp = torch.rand(B, T, 21, 2, device="cuda") if m.spec.keypoints else None

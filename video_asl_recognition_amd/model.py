@@ -86,11 +86,20 @@ class AslClipModel:
         # frames per backbone launch.  Default 256 for the per-frame backbones; 1 024 for I3D (16 clips of 64 frames per
         # launch): its deep layers are a few hundred pixels per clip, and four clips per launch left most CUs without a
         # tile (16 x 64: 10.95 -> 8.01 ms per forward)
+        # A batch that fits one chunk is still divided over the streams when each part keeps at least split_frames
+        # frames (ResNet-50: 8 x 64 as 2 x 256 on two streams 8.07 ms, as 1 x 512 8.34; ResNet-18: 10 x 64 as 1 x 640
+        # 2.45 ms, as 2 x 320 2.47 -- never split)
+        self.split_frames = None
         if frames_per_chunk is None:
             # frames per backbone launch: enough that the late, small layers fill whole rounds of workgroups (ResNet-18:
-            # 640 frames = 1 960 / 980 / 256 tiles on 512 / 512 / 256 slots; I3D: 16 clips); ResNet-50 is flat in it
-            frames_per_chunk = {"i3d": 1024, "resnet18": 640}.get(self.spec.backbone, 256)
+            # 640 frames = 1 960 / 980 / 256 tiles on 512 / 512 / 256 slots; I3D: 16 clips; ResNet-50: 16 x 64 as
+            # 2 x 512 15.3 ms, as 4 x 256 15.55, 32 x 64 29.1 against 29.55)
+            frames_per_chunk = {"i3d": 1024, "resnet18": 640, "resnet50": 512}.get(self.spec.backbone, 256)
+            if self.spec.backbone == "resnet50":
+                self.split_frames = 256
         self.frames_per_chunk = int(frames_per_chunk)
+        if self.split_frames is None:
+            self.split_frames = self.frames_per_chunk
         self.streams = int(streams)
         self._streams: List[torch.cuda.Stream] = []
         self._i3d_events: List[torch.cuda.Event] = []
@@ -383,7 +392,7 @@ class AslClipModel:
         if self.spec.temporal == "bilstm":
             ld_b, lo_off = 2 * F, F
         feats_b = torch.empty(n_total, ld_b, dtype=torch.bfloat16, device=self.device) if want_bf16 else None
-        nstreams = max(1, min(self.streams, (n_total + self.frames_per_chunk - 1) // self.frames_per_chunk))
+        nstreams = max(1, min(self.streams, (n_total + self.split_frames - 1) // self.split_frames))
         step = min(self.frames_per_chunk, (n_total + nstreams - 1) // nstreams)
         if chunk_head is not None:
             step = (step + T - 1) // T * T              # whole clips per chunk
