@@ -53,6 +53,13 @@ __global__ __launch_bounds__(64) void lstm_step_mfma_kernel(const LstmMfmaArgs a
         const bool colok = bcol < a.B;
         const short* hrow = a.h_prev + ((long long)d * a.B + (colok ? bcol : 0)) * H + fq * 8;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // the input projection's four gate terms and the cell state of this lane's (unit, batch row) are asked for first:
+        // loaded after the MFMAs they would be one more memory round trip on the step's dependency chain
+        const int bq = colok ? bcol : 0;
+        const float* gxp = a.gx + ((long long)bq * a.T + t) * a.ld_gx + d * 4 * H + j0 + fq;
+        const long long si = ((long long)d * a.B + bq) * H + j0 + fq;
+        const float gx0 = gxp[0], gx1 = gxp[H], gx2 = gxp[2 * H], gx3 = gxp[3 * H];
+        const float c_prev = a.c[si];
         // eight k-steps of loads (24 x 16 bytes per lane) are issued before their MFMAs: the step is a latency
         // chain, so it wants every load of a batch in flight at once
         for (int ks0 = 0; ks0 < ksteps; ks0 += 8) {
@@ -75,13 +82,11 @@ __global__ __launch_bounds__(64) void lstm_step_mfma_kernel(const LstmMfmaArgs a
         // lane (fr, fq) holds gates i, f, g, o of unit j0 + fq for batch row b0 + fr
         if (colok) {
             const int b = bcol, j = j0 + fq;
-            const float* gx = a.gx + ((long long)b * a.T + t) * a.ld_gx + d * 4 * H + j;
-            const float gi = sigmoidf_(acc[0] + gx[0]);
-            const float gf = sigmoidf_(acc[1] + gx[H]);
-            const float gg = tanhf_(acc[2] + gx[2 * H]);
-            const float go = sigmoidf_(acc[3] + gx[3 * H]);
-            const long long si = ((long long)d * a.B + b) * H + j;
-            const float cn = gf * a.c[si] + gi * gg;
+            const float gi = sigmoidf_(acc[0] + gx0);
+            const float gf = sigmoidf_(acc[1] + gx1);
+            const float gg = tanhf_(acc[2] + gx2);
+            const float go = sigmoidf_(acc[3] + gx3);
+            const float cn = gf * c_prev + gi * gg;
             const float hn = go * tanhf_(cn);
             a.c[si] = cn;
             const short hi = f32_to_bf16(hn);
