@@ -722,6 +722,9 @@ def test_maxpool_exact(gpu):
                                          # (it takes launches of 64 k lanes and more)
                                          ((3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 19, 30, 30, 512)),
                                          ((3, 3, 3), (1, 1, 1), (0, 0, 0), (3, 12, 29, 27, 512)),
+                                         # rows of 28 and 21 outputs: seven per lane instead of four
+                                         ((3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 19, 28, 28, 512)),
+                                         ((3, 3, 3), (1, 1, 1), (0, 0, 0), (4, 12, 29, 23, 512)),
                                          ((2, 2, 2), (2, 2, 2), (0, 0, 0), (2, 8, 14, 14, 832)),
                                          ((2, 3, 2), (1, 2, 1), (0, 1, 0), (1, 4, 9, 7, 16))])
 def test_maxpool3d_exact(gpu, k, s, p, shape):

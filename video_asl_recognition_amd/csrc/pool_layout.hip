@@ -790,7 +790,9 @@ extern "C" int asl_maxpool3d_ndhwc(const asl_pool3d_params* p, const void* x, vo
     // (rolling over depth pays once there are lanes enough to hide its serial walk: below ~64 k lanes the per-output kernel)
     if (a.kd == 3 && a.kh == 3 && a.kw == 3 && a.sd == 1 && a.sh == 1 && a.sw == 1 &&
         (long long)a.n * ((a.od + 7) / 8) * a.oh * ((a.ow + 3) / 4) * a.c8 >= 65536)
-        e = launch_maxpool333_roll<4, 8>(a, (hipStream_t)stream);
+        // seven outputs per lane where rows divide by seven (28, 14: 27 loads per plane for seven outputs instead of 18 for
+        // four; 29-33 us against 36-43 at 14 x 14, 98 / 129 against 104 / 145 at 28 x 28; fourteen per lane is slower again)
+        e = a.ow % 7 == 0 ? launch_maxpool333_roll<7, 8>(a, (hipStream_t)stream) : launch_maxpool333_roll<4, 8>(a, (hipStream_t)stream);
     else if (a.kd == 3 && a.kh == 3 && a.kw == 3 && a.sw == 1) e = launch_maxpool_fixed<3, 3, 3, 1, 4>(a, (hipStream_t)stream);
     else if (a.kd == 3 && a.kh == 3 && a.kw == 3 && a.sw == 2) e = launch_maxpool_fixed<3, 3, 3, 2, 2>(a, (hipStream_t)stream);
     else if (a.kd == 1 && a.kh == 3 && a.kw == 3 && a.sw == 2) e = launch_maxpool_fixed<1, 3, 3, 2, 2>(a, (hipStream_t)stream);
