@@ -7,7 +7,8 @@ python tools/pmc_summary.py [--json out.json --frames-per-chunk N] a.csv b.csv .
 With --json, also writes the figures bench.py reports next to its timing: HBM bytes of the headline path's kernels
 per chunk of frames -- the stem launch that reads the clips in place (once per chunk) plus, for the kernels the
 uint8-frames leg of the bench shares (blocks, convolutions, pools, head), their bytes per launch x launches per chunk
-over both legs; the kernels only that leg runs (preprocess, packed-input stem, pack, softmax) are left out --
+over both legs; the kernels only that leg runs (resize, softmax; a packed-input stem and pack when ASL_PLANAR_STEM=0) are
+left out --
 and the MFMA-busy ratio of the conv kernels, SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x busy cycles), busy
 cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs)."""
 import csv
