@@ -409,7 +409,9 @@ int asl_lstm_bidir_layer(const asl_lstm_params* p, const float* gx, const void* 
  *   - 6 * batch * hidden must not exceed ASL_LSTM_STATIC_STATE_FLOATS (e.g. batch 128 at hidden 512,
  *     batch 64 at hidden 1024); larger requests return ASL_ETOOBIG and launch nothing.
  *   - The array's address is looked up on the first call made with a given device current
- *     (hipGetSymbolAddress); make that first call outside graph capture.
+ *     (hipGetSymbolAddress); make that first call outside graph capture.  Later calls consist of
+ *     kernel launches only (the state is zeroed by a kernel, not by hipMemsetAsync) and can be
+ *     captured into a HIP graph and replayed.
  *   - All calls on one GPU share the array: it is zeroed at the start of every call, and two calls
  *     that overlap on one GPU (different streams, or threads) race.  Serialize them.
  * Arguments, outputs and arithmetic are otherwise those of asl_lstm_bidir_layer (bit-identical). */

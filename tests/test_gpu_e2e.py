@@ -191,6 +191,36 @@ def test_chunking_and_streams_do_not_change_results(gpu):
         del m
 
 
+@pytest.mark.parametrize("name,B,T", [("resnet18_mean", 3, 8), ("resnet50_bilstm", 2, 16), ("i3d", 2, 16),
+                                      ("twostream_transformer", 2, 32)])
+def test_forward_replays_from_a_hip_graph(gpu, name, B, T):
+    """A forward captured with torch.cuda.graph (chunk streams, branch streams and their events, the LSTM's per-step
+    launches and memsets all inside the capture) replays on new input contents and gives what a direct forward gives."""
+    from video_asl_recognition_amd import AslClipModel
+    m = AslClipModel(name, seed=6)
+    S = m.spec.size
+    static = O.make_clips(B, T, S, 1).cuda().to(torch.bfloat16)
+    kp = O.make_keypoints(B, T, 2).cuda() if m.spec.keypoints else None
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                               # warm-up off the default stream: plans, streams, LDS sizes
+        for _ in range(2):
+            m(static, kp)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(static, kp)
+    for seed in (3, 4):
+        fresh = O.make_clips(B, T, S, seed).cuda().to(torch.bfloat16)
+        static.copy_(fresh)
+        g.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        ref = m(fresh, kp)
+        assert bool(torch.isfinite(got).all()) and torch.equal(got, ref)
+
+
 def test_classify_clip_resizes_into_the_clip_tensor_the_stem_reads(gpu, monkeypatch):
     """uint8 frames are resized and normalised straight into bf16 clips [n][3][S][S], which the stem reads in place:
     the logits are those of forward(preprocess(frames)) bit for bit (ragged chunks, two streams, two calls), and the

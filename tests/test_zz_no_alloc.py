@@ -91,3 +91,32 @@ def test_static_state_lstm_matches_nn_lstm(gpu):
     # hi + lo halves of h carry ~16 mantissa bits; tolerance as in the kernel's own test against nn.LSTM
     torch.testing.assert_close(yy[..., :2 * H] + yy[..., 2 * H:], ref, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(ysum, ref.mean(1), rtol=1e-4, atol=1e-5)
+
+
+def test_static_state_lstm_replays_from_a_hip_graph(gpu):
+    """The use the entry point exists for: a call captured into a HIP graph (nothing in it allocates; its state is zeroed
+    by a kernel of the library) and replayed several times, each time on new contents of the same input buffer, against
+    direct calls.  The first call on the device is made outside the capture (it looks the array's address up)."""
+    from video_asl_recognition_amd import _lib as L
+    B, T, H = 3, 12, 64
+    gx0, w_hh = _inputs(B, T, H, 41)
+    _run(L, B, T, H, gx0, w_hh, static=True)
+    gx = gx0.clone()
+    y = torch.full((B * T, 4 * H), 7.0, dtype=torch.bfloat16, device="cuda")
+    ysum = torch.full((B, 2 * H), 7.0, device="cuda")
+    p = L.LstmParams(batch=B, t=T, hidden=H, ld_gx=8 * H, ld_y=4 * H, split_y=1, ysum_scale=1.0 / T)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(L.lib.asl_lstm_bidir_layer_static(C.byref(p), _p(gx), _p(w_hh), _p(y), _p(ysum), stream), "lstm static")
+    for seed in (42, 43, 44):
+        fresh, _ = _inputs(B, T, H, seed)
+        gx.copy_(fresh)
+        y.fill_(7.0)
+        ysum.fill_(7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        y_ref, s_ref = _run(L, B, T, H, fresh, w_hh, static=False)
+        assert torch.equal(y.cpu().view(torch.int16), y_ref.view(torch.int16)), f"y differs on replay with seed {seed}"
+        assert torch.equal(ysum.cpu(), s_ref), f"ysum differs on replay with seed {seed}"

@@ -330,6 +330,17 @@ int grid_rows(long long total) {
 }  // namespace asl_detail
 using namespace asl_detail;
 
+// Zero-fill of the recurrent state and the running sum as a kernel of the library, not hipMemsetAsync: a memset node in
+// a captured HIP graph zeroes on the first replay only on this ROCm release (later replays write an arbitrary byte
+// pattern), and the LSTM entry points are meant to be capturable.  p: n4 16-byte units; q: m floats (any alignment).
+namespace asl_detail {
+__global__ __launch_bounds__(256) void zero_fill_kernel(f32x4* __restrict__ p, long long n4, float* __restrict__ q, long long m) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    else if (i - n4 < m) q[i - n4] = 0.f;
+}
+}  // namespace asl_detail
+
 // Shared body of the two LSTM entry points: validates, zeroes the state, issues one launch per step.
 static int lstm_run(const asl_lstm_params* p, const float* gx, const void* w_hh, void* y_bf16, float* ysum,
                     float* state, hipStream_t s) {
@@ -339,12 +350,10 @@ static int lstm_run(const asl_lstm_params* p, const float* gx, const void* w_hh,
     if (p->ld_gx < 8 * p->hidden || p->ld_y < (p->split_y ? 4 : 2) * p->hidden) return ASL_EINVAL;
     if (((uintptr_t)w_hh & 15) || ((uintptr_t)state & 15)) return ASL_EINVAL;
     const long long n = 2LL * p->batch * p->hidden;           // elements of one [2][B][H] state array
-    // state = h ping | h pong | c ; zero initial state, and the running sum if requested
-    hipError_t e = hipMemsetAsync(state, 0, (size_t)(3 * n) * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-    if (ysum) {
-        e = hipMemsetAsync(ysum, 0, (size_t)n * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
+    // state = h ping | h pong | c ; zero initial state, and the running sum if requested (n is a multiple of 64)
+    {
+        const long long n4 = 3 * n / 4, m = ysum ? n : 0;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n4 + m + 255) / 256)), dim3(256), 0, s, (f32x4*)state, n4, ysum, m);
     }
     {
         // the two h arrays of `state` hold bf16 (hi | lo) planes of [2][B][H] each: 2*B*H floats' worth of bytes
@@ -373,7 +382,7 @@ extern "C" int asl_lstm_bidir_layer(const asl_lstm_params* p, const float* gx, c
 // part of the library's code object, so the caller brings no scratch and nothing here allocates.
 // Every GPU the library runs on holds its own copy of the array (1.5 MiB) at its own address; the
 // address is looked up once per device, on the first call made with that device current, and only
-// that looked-up pointer is ever handed to hipMemsetAsync or a kernel -- the array's name in host
+// that looked-up pointer is ever handed to a kernel -- the array's name in host
 // code is not a device address.
 // ---------------------------------------------------------------------------------------------
 static __device__ __align__(256) float scratch[ASL_LSTM_STATIC_STATE_FLOATS];
