@@ -285,6 +285,26 @@ int asl_conv1x1_dual_bf16(const asl_dual1x1_params* p, const void* t, const void
                           const float* scale, const float* bias, const float* pre_scale, void* y,
                           asl_stream_t stream);
 
+/* The exit of one ResNet bottleneck and the entry of the next, two 1x1 convolutions, in one launch:
+ *     y  = relu( bn_a(conv_a(t)) + res )     conv_a: nn.Conv2d(cin, cmid, 1)   (a block's conv3 + bn3 + shortcut + ReLU)
+ *     y2 = relu( bn_b(conv_b(y)) )           conv_b: nn.Conv2d(cmid, cout, 1)  (the next block's conv1 + bn1 + ReLU)
+ * y is written as usual (it is the next block's shortcut) and, as bf16, stays on the chip as conv_b's operand: both
+ * outputs equal those of two asl_conv2d_nhwc_bf16 calls bit for bit.  t: [n][h+2*in_halo][w+2*in_halo][cin];
+ * res: [..res_halo..][cmid]; y: [..mid_halo..][cmid]; y2: [..out_halo..][cout]; weights packed as for
+ * asl_conv2d_nhwc_bf16.  Built for cin = 64, cmid = 256, cout = 64 / 128 / 256 (ResNet-50's first stage and its
+ * hand-over to the second); ASL_ENOTSUP for other valid sizes. */
+typedef struct asl_chain1x1_params {
+    int32_t n, h, w;
+    int32_t cin, cmid, cout;
+    int32_t in_halo, res_halo, mid_halo, out_halo;
+    int32_t w_rows_a, w_rows_b;
+} asl_chain1x1_params;
+
+int asl_conv1x1_chain_bf16(const asl_chain1x1_params* p, const void* t, const void* w_a,
+                           const float* scale_a, const float* bias_a, const void* res, void* y,
+                           const void* w_b, const float* scale_b, const float* bias_b, void* y2,
+                           asl_stream_t stream);
+
 /* nn.Linear on bf16 rows: y[m][n] = act(scale[n] * sum_k x[m][k] w[n][k] + bias[n] (+ res)).
  * x bf16 [m][ldx] (k % 32 == 0, ldx >= k), w packed [w_rows][k], y bf16 or fp32 [m][ldy],
  * res bf16 or (res_f32) fp32 [m][ldres]. */
@@ -470,6 +490,8 @@ int asl_attention_fwd(const asl_attn_params* p, const void* qkv, void* out, asl_
  *   ASL_OP_BLOCK_ENTRY   asl_entry_params*       x2, w, scale, bias, w_ds, scale_ds, bias_ds, y, y_ds
  *   ASL_OP_MAXPOOL_SPLIT NULL                    x, y                                    n, h, w, c, in_halo, out_halo
  *   ASL_OP_CONV1X1_DUAL  asl_dual1x1_params*     t, x, w, scale, bias, pre_scale, y
+ *   ASL_OP_CONV1X1_CHAIN asl_chain1x1_params*    t, w_a, sb_a, res, y, w_b, sb_b, y2     (sb = scale[c] followed by bias[c],
+ *                        one fp32 array of 2*c values, c = cmid for sb_a and cout for sb_b, c % 4 == 0)
  *
  * Returns ASL_OK, or the first failing op's return code with its index in *failed (if failed != NULL); ops
  * before it have been issued, ops after it have not.  ASL_EINVAL for an unknown kind, a stream index outside
@@ -478,7 +500,7 @@ enum {
     ASL_OP_NOP = 0, ASL_OP_CONV2D = 1, ASL_OP_STEM_CONV = 2, ASL_OP_STEM_POOL = 3, ASL_OP_CONV3D = 4, ASL_OP_LINEAR = 5,
     ASL_OP_MAXPOOL3D = 6, ASL_OP_MAXPOOL = 7, ASL_OP_AVGPOOL = 8, ASL_OP_PACK_CLIPS = 9, ASL_OP_PREPROCESS = 10,
     ASL_OP_MEAN_T = 11, ASL_OP_HEAD = 12, ASL_OP_BASIC_BLOCK = 13, ASL_OP_BLOCK_ENTRY = 14, ASL_OP_MAXPOOL_SPLIT = 15,
-    ASL_OP_CONV1X1_DUAL = 16
+    ASL_OP_CONV1X1_DUAL = 16, ASL_OP_CONV1X1_CHAIN = 17
 };
 
 typedef struct asl_op {

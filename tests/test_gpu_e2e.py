@@ -299,6 +299,22 @@ def test_fused_basic_blocks_give_the_same_logits(gpu, monkeypatch):
     assert rel_l2(y1, y0) <= 5e-4       # different summation order inside the MFMAs: a few bf16 roundings flip
 
 
+def test_resnet50_fused_exits_give_the_same_logits(gpu, monkeypatch):
+    """ResNet-50 with a bottleneck's last 1x1 conv and the next block's first one in one launch (56 x 56 stage) gives, bit
+    for bit, the logits of the plan that launches them apart."""
+    from video_asl_recognition_amd import AslClipModel
+    from video_asl_recognition_amd import _lib as L
+    clips = O.make_clips(2, 8, 224, 5).cuda()
+    m = AslClipModel("resnet50_bilstm", seed=9)
+    kinds = [int(r["op"].kind) for r in m._get_plans(16, 1)[0]["ops"]]
+    assert kinds.count(L.OP_CONV1X1_CHAIN) == 2 and kinds.count(L.OP_CONV1X1_DUAL) == 4
+    y = m(clips).clone()
+    monkeypatch.setenv("ASL_CHAIN_1X1", "0")
+    m1 = AslClipModel("resnet50_bilstm", seed=9)
+    assert L.OP_CONV1X1_CHAIN not in [int(r["op"].kind) for r in m1._get_plans(16, 1)[0]["ops"]]
+    assert torch.equal(m1(clips), y)
+
+
 def test_single_frame_single_clip(gpu):
     """smallest clip the surface accepts: B=1, T=1"""
     om, m = _model("resnet18_mean")

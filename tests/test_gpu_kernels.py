@@ -149,6 +149,58 @@ def test_conv1x1_dual(gpu, n, h, w, cin, cin2, cout, stride2, ih, ih2, oh_, ctot
     assert L.lib.asl_conv1x1_dual_bf16(C.byref(bad), *args[1:]) == L.ASL_ENOTSUP
 
 
+@pytest.mark.parametrize("n,h,w,cout,ih,rh,mh,oh_", [(2, 8, 8, 64, 1, 0, 0, 1), (3, 7, 9, 128, 0, 1, 1, 1), (1, 5, 5, 256, 1, 1, 0, 0),
+                                                     (5, 28, 28, 64, 1, 1, 1, 1), (4, 56, 56, 128, 1, 0, 0, 1)])
+def test_conv1x1_chain(gpu, n, h, w, cout, ih, rh, mh, oh_):
+    """asl_conv1x1_chain_bf16 against the two asl_conv2d_nhwc_bf16 launches it stands for: both outputs bit for bit (halos
+    untouched included), on tiles with a ragged last workgroup, every pairing of halos, all three output widths."""
+    from video_asl_recognition_amd import _lib as L
+    from video_asl_recognition_amd.packing import pack_conv
+    cin, cmid = 64, 256
+    g = torch.Generator().manual_seed(h * 31 + cout)
+    t = _bf16(torch.randn(n, cin, h, w, generator=g))
+    r = _bf16(torch.randn(n, cmid, h, w, generator=g))
+    wa = _bf16(torch.randn(cmid, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5)
+    wb = _bf16(torch.randn(cout, cmid, 1, 1, generator=g) * (2.0 / cmid) ** 0.5)
+    sa, ba = torch.empty(cmid).uniform_(0.5, 1.5, generator=g), torch.empty(cmid).normal_(0, 0.1, generator=g)
+    sb, bb = torch.empty(cout).uniform_(0.5, 1.5, generator=g), torch.empty(cout).normal_(0, 0.1, generator=g)
+    pa = pack_conv(wa, "cuda", scale=sa.cuda(), bias=ba.cuda())
+    pb = pack_conv(wb, "cuda", scale=sb.cuda(), bias=bb.cuda())
+    td, rd = _halo(t, ih), _halo(r, rh)
+    # reference: the two launches
+    y_ref = torch.full((n, h + 2 * mh, w + 2 * mh, cmid), 5.0, dtype=torch.bfloat16, device="cuda")
+    y2_ref = torch.full((n, h + 2 * oh_, w + 2 * oh_, cout), 5.0, dtype=torch.bfloat16, device="cuda")
+    p1 = L.Conv2dParams(n=n, h=h, w=w, cin=cin, in_halo=ih, cout=cmid, kh=1, kw=1, stride=1, pad=0, out_halo=mh, out_ctot=cmid,
+                        out_coff=0, res_halo=rh, res_ctot=cmid, res_coff=0, relu=1, w_rows=pa.w_rows, variant=0, out_s2d=0, out_split=0)
+    L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(p1), _p(td), _p(pa.w), _p(pa.scale), _p(pa.bias), _p(rd), _p(y_ref), None), "a")
+    p2 = L.Conv2dParams(n=n, h=h, w=w, cin=cmid, in_halo=mh, cout=cout, kh=1, kw=1, stride=1, pad=0, out_halo=oh_, out_ctot=cout,
+                        out_coff=0, res_halo=0, res_ctot=0, res_coff=0, relu=1, w_rows=pb.w_rows, variant=0, out_s2d=0, out_split=0)
+    L.check(L.lib.asl_conv2d_nhwc_bf16(C.byref(p2), _p(y_ref), _p(pb.w), _p(pb.scale), _p(pb.bias), None, _p(y2_ref), None), "b")
+    y = torch.full_like(y_ref, 5.0)
+    y2 = torch.full_like(y2_ref, 5.0)
+    p = L.Chain1x1Params(n=n, h=h, w=w, cin=cin, cmid=cmid, cout=cout, in_halo=ih, res_halo=rh, mid_halo=mh, out_halo=oh_,
+                         w_rows_a=pa.w_rows, w_rows_b=pb.w_rows)
+    args = (C.byref(p), _p(td), _p(pa.w), _p(pa.scale), _p(pa.bias), _p(rd), _p(y), _p(pb.w), _p(pb.scale), _p(pb.bias), _p(y2), None)
+    L.check(L.lib.asl_conv1x1_chain_bf16(*args), "chain")
+    torch.cuda.synchronize()
+    # sanity of the reference itself against torch
+    v = lambda a: a.view(1, -1, 1, 1)
+    ref1 = F.relu(F.conv2d(t, wa) * v(sa) + v(ba) + r)
+    got1 = y_ref[:, mh:mh + h, mh:mh + w].float().cpu().permute(0, 3, 1, 2)
+    assert float((got1 - ref1).abs().max()) < 0.1
+    assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)), "y differs from the two-launch form"
+    assert torch.equal(y2.view(torch.int16), y2_ref.view(torch.int16)), "y2 differs from the two-launch form"
+    assert float(y2_ref[:, oh_:oh_ + h, oh_:oh_ + w].float().abs().max()) > 0
+    # sizes the kernel is not built for are refused, not run
+    bad = L.Chain1x1Params(n=n, h=h, w=w, cin=128, cmid=512, cout=128, in_halo=ih, res_halo=rh, mid_halo=mh, out_halo=oh_,
+                           w_rows_a=512, w_rows_b=128)
+    assert L.lib.asl_conv1x1_chain_bf16(C.byref(bad), *args[1:]) == L.ASL_ENOTSUP
+    bad = L.Chain1x1Params(n=n, h=h, w=w, cin=cin, cmid=cmid, cout=cout, in_halo=-1, res_halo=rh, mid_halo=mh, out_halo=oh_,
+                           w_rows_a=pa.w_rows, w_rows_b=pb.w_rows)
+    assert L.lib.asl_conv1x1_chain_bf16(C.byref(bad), *args[1:]) == L.ASL_EINVAL
+    assert L.lib.asl_conv1x1_chain_bf16(C.byref(p), None, *args[2:]) == L.ASL_EINVAL
+
+
 def test_forced_variant_that_does_not_fit_is_refused(gpu):
     from video_asl_recognition_amd import _lib as L
     for variant in (L.CONV_C64, L.CONV_PP, L.CONV_WIDE):      # a 1x1 conv fits none of the 3x3 kernels

@@ -31,6 +31,10 @@ def describe(rec, n):
         macs = n * p.h * p.w * p.cout * (p.cin + p.cin2)
         byts = 2 * n * p.h * p.w * (p.cin + p.cin2 + p.cout)
         return f"1x1 {p.cin:4d}->{p.cout:4d} @{p.h}x{p.w} + shortcut 1x1/{p.stride2} {p.cin2:4d}->{p.cout:4d}", macs, byts
+    if kind == L.OP_CONV1X1_CHAIN:
+        macs = n * p.h * p.w * p.cmid * (p.cin + p.cout)
+        byts = 2 * n * p.h * p.w * (p.cin + 2 * p.cmid + p.cout)
+        return f"1x1 {p.cin:4d}->{p.cmid:4d} +res, then 1x1 ->{p.cout:4d} @{p.h}x{p.w}", macs, byts
     if kind == L.OP_BASIC_BLOCK:
         macs = 2 * n * p.h * p.w * 64 * 64 * 9
         return f"block 64 @{p.h}x{p.w}", macs, 2 * n * p.h * p.w * 64 * 2

@@ -70,6 +70,11 @@ class Dual1x1Params(C.Structure):
                                         "out_ctot", "out_coff", "relu", "w_rows")]
 
 
+class Chain1x1Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "cin", "cmid", "cout", "in_halo", "res_halo", "mid_halo", "out_halo",
+                                        "w_rows_a", "w_rows_b")]
+
+
 class LinearParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("m", "n", "k", "ldx", "ldy", "ldres", "relu", "out_f32", "res_f32", "w_rows")]
 
@@ -92,7 +97,7 @@ class Op(C.Structure):
 
 OP_NOP = 0
 (OP_CONV2D, OP_STEM_CONV, OP_STEM_POOL, OP_CONV3D, OP_LINEAR, OP_MAXPOOL3D, OP_MAXPOOL, OP_AVGPOOL, OP_PACK_CLIPS,
- OP_PREPROCESS, OP_MEAN_T, OP_HEAD, OP_BASIC_BLOCK, OP_BLOCK_ENTRY, OP_MAXPOOL_SPLIT, OP_CONV1X1_DUAL) = range(1, 17)
+ OP_PREPROCESS, OP_MEAN_T, OP_HEAD, OP_BASIC_BLOCK, OP_BLOCK_ENTRY, OP_MAXPOOL_SPLIT, OP_CONV1X1_DUAL, OP_CONV1X1_CHAIN) = range(1, 18)
 
 
 class AttnParams(C.Structure):
@@ -125,6 +130,7 @@ _PROTOS = {
     "asl_conv3d_ndhwc_bf16": ([C.POINTER(Conv3dParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_stem3d_bf16": ([C.POINTER(Stem3dParams), _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_conv1x1_dual_bf16": ([C.POINTER(Dual1x1Params), _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "asl_conv1x1_chain_bf16": ([C.POINTER(Chain1x1Params)] + [_P] * 11, C.c_int),
     "asl_linear_bf16": ([C.POINTER(LinearParams), _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "asl_pack_clips": ([_P, _I, _I, _I, _I, _P, _P], C.c_int),
     "asl_pack_clips_3d": ([_P, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),

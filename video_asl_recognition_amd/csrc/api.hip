@@ -224,6 +224,14 @@ extern "C" int asl_run_ops(const asl_op* ops, int count, const asl_stream_t* str
                     rc = asl_conv1x1_dual_bf16((const asl_dual1x1_params*)o.params, p[0], p[1], p[2], (const float*)p[3],
                                                (const float*)p[4], (const float*)p[5], p[6], s);
                     break;
+                case ASL_OP_CONV1X1_CHAIN: {
+                    const asl_chain1x1_params* cp = (const asl_chain1x1_params*)o.params;
+                    if (!cp || !p[2] || !p[6]) { rc = ASL_EINVAL; break; }
+                    const float* sa = (const float*)p[2];
+                    const float* sb = (const float*)p[6];
+                    rc = asl_conv1x1_chain_bf16(cp, p[0], p[1], sa, sa + cp->cmid, p[3], p[4], p[5], sb, sb + cp->cout, p[7], s);
+                    break;
+                }
                 default:
                     rc = ASL_EINVAL;
             }

@@ -81,9 +81,13 @@ __device__ __forceinline__ void epilogue_prepare(EpiState<FM, FN>& st, const Out
 // SPLIT (the parity mode's split-precision activations): the bf16 output is written as two halves, hi = bf16(v) at the
 // usual place and lo = bf16(v - hi) out_lo elements further on, so hi + lo carries v to ~16 mantissa bits; a residual is
 // read the same way (its lo half res_lo elements further on) when it is used, not ahead of the K loop.
-template <int FM, int FN, bool SPLIT = false>
+// TOLDS: every 8-channel bf16 vector stored to memory is also written to a row-major LDS tile (row = the pixel's index
+// within the workgroup's tile, lds_row0 = this wave's first row, lds_row_bytes per row, channel ch at byte 2 * ch), where
+// a second GEMM of the same launch reads it as its operand; whole 8-channel groups only.
+template <int FM, int FN, bool SPLIT = false, bool TOLDS = false>
 __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char* stage, const OutGeom& g,
-                                               const EpiState<FM, FN>& st, int lane) {
+                                               const EpiState<FM, FN>& st, int lane, char* lds_tile = nullptr,
+                                               int lds_row0 = 0, int lds_row_bytes = 0) {
     using S = EpiState<FM, FN>;
     constexpr int ROWB = kEpiRowBytes(S::WTN);
     const int fr = lane & 15, fq = lane >> 4;
@@ -141,6 +145,7 @@ __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[FM][FN], char*
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ov[e] = f32_to_bf16(v0[e]); ov[4 + e] = f32_to_bf16(v1[e]); }
                     *(bf16x8*)(g.y + 2 * o) = ov;
+                    if constexpr (TOLDS) *(bf16x8*)(lds_tile + (lds_row0 + i * 16 + pr) * lds_row_bytes + 2 * ch) = ov;
                     if constexpr (SPLIT) {
                         bf16x8 lv;
 #pragma unroll

@@ -126,6 +126,9 @@ class AslClipModel:
         # ResNet stem straight from the bf16 clip tensor (no packed, halo'd copy of the input): ASL_PLANAR_STEM=0 goes
         # back to pack + packed-input stem (and uint8 frames are then resized into the packed form instead of into clips)
         self.planar_stem = os.environ.get("ASL_PLANAR_STEM", "1") != "0"
+        # ResNet-50, 56 x 56 stage: a bottleneck's last 1x1 conv (+ shortcut + ReLU) and the next bottleneck's first 1x1 conv
+        # as one launch; ASL_CHAIN_1X1=0 keeps them apart (same results bit for bit)
+        self.chain_1x1 = os.environ.get("ASL_CHAIN_1X1", "1") != "0"
         # BiLSTM / transformer heads per chunk of whole clips, on the chunk's stream, under the other stream's backbone
         # launches instead of one head over the whole batch after the backbone.  Opt-in (argument, or ASL_CHUNK_HEADS=1):
         # measured no faster -- ResNet-50 + BiLSTM 16 x 64 17.65 against 16.39 ms (the recurrence's 128 short launches
@@ -274,6 +277,7 @@ class AslClipModel:
             basic = RESNET_LAYERS[spec.backbone][0] == "basic"
             blocks = list(resnet_blocks(spec.backbone))
             cells_ok = basic and self.s2d_entry and self.conv_variant in (0, L.CONV_PP) and not pm
+            t1_pre = None                                         # a bottleneck's conv1 output, when the block before wrote it
             for bi, (prefix, cin, planes, stride, ds) in enumerate(blocks):
                 oh, ow = x.h // stride, x.w // stride
                 w = self._w
@@ -312,8 +316,11 @@ class AslClipModel:
                     conv_op(w[prefix + ".conv2"], t, y, 1, 1, True, res=idt)
                     pool.put(t)
                 else:
-                    t1 = pool.get(x.h, x.w, planes * cm)
-                    conv_op(w[prefix + ".conv1"], x, t1, 1, 0, True)
+                    if t1_pre is not None:                        # written by the previous block's last launch
+                        t1, t1_pre = t1_pre, None
+                    else:
+                        t1 = pool.get(x.h, x.w, planes * cm)
+                        conv_op(w[prefix + ".conv1"], x, t1, 1, 0, True)
                     t2 = pool.get(oh, ow, planes * cm)
                     conv_op(w[prefix + ".conv2"], t1, t2, stride, 1, True)
                     idt = x
@@ -324,6 +331,17 @@ class AslClipModel:
                         dp = L.Dual1x1Params(n=0, h=oh, w=ow, cin=t2.c, in_halo=t2.halo, cin2=x.c, in2_halo=x.halo, stride2=stride,
                                              cout=pc.cout, out_halo=y.halo, out_ctot=y.c, out_coff=0, relu=1, w_rows=pc.w_rows)
                         add(L.OP_CONV1X1_DUAL, dp, (t2.t, x.t, pc.w, pc.scale, pc.bias, pre, y.t), conv=True, keep=(t2, x, y, pc, pre))
+                    elif (self.chain_1x1 and not ds and not pm and nxt is not None and self.conv_variant in (0, L.CONV_GATHER)
+                          and t2.c == 64 and y.c == 256 and nxt[2] in (64, 128, 256)):
+                        # conv3 + shortcut of this block and conv1 of the next in one launch (asl_conv1x1_chain_bf16): the
+                        # 256-channel tensor is written once and not read back for the next block's first conv
+                        ca, cb = w[prefix + ".conv3"], w[nxt[0] + ".conv1"]
+                        t1_pre = pool.get(oh, ow, nxt[2])
+                        sba, sbb = torch.cat([ca.scale, ca.bias]).contiguous(), torch.cat([cb.scale, cb.bias]).contiguous()
+                        cp = L.Chain1x1Params(n=0, h=oh, w=ow, cin=t2.c, cmid=y.c, cout=nxt[2], in_halo=t2.halo, res_halo=x.halo,
+                                              mid_halo=y.halo, out_halo=t1_pre.halo, w_rows_a=ca.w_rows, w_rows_b=cb.w_rows)
+                        add(L.OP_CONV1X1_CHAIN, cp, (t2.t, ca.w, sba, x.t, y.t, cb.w, sbb, t1_pre.t), conv=True,
+                            keep=(t2, x, y, t1_pre, ca, cb, sba, sbb))
                     else:
                         if ds:
                             idt = pool.get(oh, ow, planes * 4 * cm)
