@@ -219,6 +219,12 @@ def test_forward_replays_from_a_hip_graph(gpu, name, B, T):
         got = out.clone()
         ref = m(fresh, kp)
         assert bool(torch.isfinite(got).all()) and torch.equal(got, ref)
+    # the same through AslClipModel.capture
+    cap = m.capture(B, T)
+    fresh = O.make_clips(B, T, S, 7).cuda()
+    assert torch.equal(cap(fresh, kp).clone(), m(fresh, kp))
+    with pytest.raises(ValueError, match="captured for clips"):
+        cap(fresh[:1], kp)
 
 
 def test_classify_clip_resizes_into_the_clip_tensor_the_stem_reads(gpu, monkeypatch):

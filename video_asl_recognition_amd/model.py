@@ -721,12 +721,53 @@ class AslClipModel:
                                         stream), "preprocess")
         return out
 
+    def capture(self, B: int, T: int) -> "CapturedForward":
+        """forward() for one batch shape as a HIP graph: see CapturedForward."""
+        return CapturedForward(self, B, T)
+
     def workspace_bytes(self) -> int:
         if self._plan is None:
             return 0
         if isinstance(self._plan, list):
             return sum(p["pool"].nbytes() + p["x0"].numel() * 2 for p in self._plan)
         return sum(p.nbytes() for p in self._i3d_plans)
+
+
+class CapturedForward:
+    """model.forward for one (B, T), captured once into a HIP graph (chunk streams, branch streams, their events and the
+    recurrence's per-step launches included) and replayed per call: the host issues one graph launch instead of every
+    kernel.  Dependent kernels start no sooner inside a graph than behind one another on a stream, so this pays where
+    issuing the launches costs the host about as long as the GPU runs them (I3D 1 x 64: 1.07 -> 0.99 ms), not at
+    throughput batch sizes.  Inputs are copied into the captured buffers; the returned logits are the captured output
+    tensor, overwritten by the next call."""
+
+    def __init__(self, model: "AslClipModel", B: int, T: int):
+        spec, dev = model.spec, model.device
+        self.model = model
+        self.clips = torch.zeros(B, T, 3, spec.size, spec.size, dtype=torch.bfloat16, device=dev)
+        self.keypoints = torch.zeros(B, T, 21, 2, dtype=torch.float32, device=dev) if spec.keypoints else None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # plans, streams and LDS-size attributes come into being outside the capture
+            for _ in range(2):
+                model(self.clips, self.keypoints)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logits = model(self.clips, self.keypoints)
+
+    @torch.no_grad()
+    def __call__(self, clips: torch.Tensor, keypoints: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if tuple(clips.shape) != tuple(self.clips.shape):
+            raise ValueError(f"captured for clips {tuple(self.clips.shape)}, got {tuple(clips.shape)}")
+        if (self.keypoints is None) != (keypoints is None):
+            raise ValueError("keypoints: the captured model " + ("takes" if self.keypoints is not None else "does not take") + " them")
+        self.clips.copy_(clips)
+        if keypoints is not None:
+            self.keypoints.copy_(keypoints)
+        self.graph.replay()
+        return self.logits
 
 
 def init_state_dict(spec: ModelSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
